@@ -1,0 +1,119 @@
+/*
+ * libvist3a_hip.so — C ABI of the MI355X (gfx950) kernels behind the VIST3A text->3DGS inference path.
+ *
+ * The reference (gohyojun15/VIST3A) has no FFI layer: its "operator API" for this path is the PyTorch
+ * nn.Module surface.  Every entry point below replaces the ATen/cuDNN/SDPA call(s) the
+ * reference reaches at the cited file:line; the Python host in vist3a_amd/ calls them through ctypes with
+ * raw device pointers.  Conventions:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted;
+ *   - `stream` is a hipStream_t passed as void*; calls are stream-ordered, re-entrant, allocate nothing;
+ *   - return 0 on success, negative V3A_ERR_* otherwise; never throws;
+ *   - bf16 tensors are raw uint16 storage (round-to-nearest-even, same as torch.bfloat16).
+ */
+#ifndef VIST3A_HIP_H
+#define VIST3A_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V3A_OK 0
+#define V3A_ERR_ARG (-1)
+#define V3A_ERR_SHAPE (-2)
+#define V3A_ERR_LAUNCH (-3)
+
+int v3a_abi_version(void);            /* bumps whenever a signature changes */
+const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue( A[M,K] . B[N,K]^T )      bf16 inputs, fp32 MFMA accumulation
+ * replaces torch.nn.Linear / F.linear under bf16 autocast:
+ *   DiT   : diffusers==0.33.1 WanAttnProcessor2_0 to_q/to_k/to_v/to_out, FeedForward net.0.proj/net.2,
+ *           condition_embedder, proj_out (call site /root/reference/inference_t23d.py:94-103)
+ *   recon : vggt/layers/attention.py:51,77 (qkv, proj), vggt/layers/mlp.py:33-38 (fc1, fc2)
+ * Epilogue order (each stage optional):  v = acc + bias ; v = bf16(v) ; v = act(v) ; v = bf16(v) ;
+ *   v = v * scale ; [v = bf16(v)] ; v = v + residual ; store as bf16 or f32.
+ * These rounding points are the ones CUDA autocast produces in the reference.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  V3A_ACT_NONE = 0,
+  V3A_ACT_GELU_TANH = 1, /* FeedForward(activation_fn="gelu-approximate") */
+  V3A_ACT_GELU_ERF = 2,  /* vggt/layers/mlp.py nn.GELU */
+  V3A_ACT_SILU = 3,
+  V3A_ACT_RELU = 4
+};
+enum {
+  V3A_GEMM_BIAS_ROW = 1 << 0,     /* bias indexed by output row (used for the V^T = Wv.X^T form) */
+  V3A_GEMM_SCALE_PER_BATCH = 1 << 1, /* scale[(row / rows_per_batch) * scale_stride + col] (AdaLN gate) else scale[col] (LayerScale) */
+  V3A_GEMM_ROUND_AFTER_SCALE = 1 << 2, /* round v*scale to bf16 before adding the residual */
+  V3A_GEMM_RES_F32 = 1 << 3,      /* residual is float32 (aggregator residual stream) else bf16 */
+  V3A_GEMM_OUT_F32 = 1 << 4,      /* store float32 else bf16 */
+  V3A_GEMM_NO_ROUND_ACC = 1 << 5  /* skip the bf16 rounding of acc+bias (fp32 heads) — NOTE: staged via bf16 unless OUT_F32 */
+};
+typedef struct {
+  const void* A;        /* bf16 [M, lda] */
+  const void* B;        /* bf16 [N, ldb] (nn.Linear weight layout) */
+  void* C;              /* bf16 or f32 [M, ldc] */
+  const float* bias;    /* f32 [N] (or [M] with BIAS_ROW); may be NULL */
+  const void* residual; /* bf16/f32 [M, ldr]; may be NULL; may alias C */
+  const float* scale;   /* f32; may be NULL */
+  int M, N, K;          /* K % 64 == 0, lda/ldb % 8 == 0, ldc % 8 == 0 */
+  int lda, ldb, ldc, ldr;
+  int rows_per_batch, scale_stride;
+  int act;              /* V3A_ACT_* */
+  int flags;            /* V3A_GEMM_* */
+  int tile;             /* -1 = auto, else index into the tile table (bench/tuning) */
+} v3a_gemm_args;
+int v3a_gemm_bf16_nt(const v3a_gemm_args* args, void* stream);
+int v3a_gemm_num_tiles(void);
+const char* v3a_gemm_tile_name(int tile);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flash attention forward (non-causal, no mask, no dropout), bf16 in/out, fp32 softmax.
+ * replaces F.scaled_dot_product_attention at
+ *   diffusers==0.33.1 WanAttnProcessor2_0 (DiT self/cross attention; call site inference_t23d.py:94-103)
+ *   /root/reference/third_party_model/anysplat/src/model/encoder/vggt/layers/attention.py:64-69
+ * Q,K: [B][N][H*D] with row stride ld* ; V is passed TRANSPOSED: vt[(h*D+d)*ldvt + b*vt_batch_stride + key],
+ * readable and finite (zero) up to the next multiple of 64 keys.  D in {64,128}.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q; const void* k; const void* vt; void* o;   /* bf16 */
+  long q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride; /* elements */
+  int ldq, ldk, ldvt, ldo;                                  /* elements */
+  int B, H, Nq, Nk, D;
+  float scale;                                              /* softmax scale, normally D^-0.5 */
+} v3a_attn_args;
+int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm in fp32 (+ optional affine) (+ optional AdaLN modulation  y = LN(x)*(1+scale[b])+shift[b]).
+ * replaces diffusers==0.33.1 FP32LayerNorm in WanTransformerBlock (norm1/norm2/norm3) and norm_out,
+ * and nn.LayerNorm at /root/reference/third_party_model/anysplat/src/model/encoder/vggt/layers/block.py:41,47.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; void* y;             /* [M, ld*]; bf16 unless *_is_f32 */
+  const float* weight; const float* bias;   /* [d] or NULL */
+  const float* scale; const float* shift;   /* [nbatch, mod_stride] or NULL (both or neither) */
+  int M, d, ldx, ldy;
+  int rows_per_batch, mod_stride;
+  float eps;
+  int x_is_f32, y_is_f32;
+} v3a_layernorm_args;
+int v3a_layernorm(const v3a_layernorm_args* args, void* stream);
+
+/* RMSNorm across the full width + optional RoPE (complex multiply of adjacent pairs, per head).
+ * replaces diffusers==0.33.1 RMSNorm (attn.norm_q / norm_k, "rms_norm_across_heads") followed by
+ * WanAttnProcessor2_0.apply_rotary_emb.  rope = float [tokens_per_batch][head_dim/2][2] = (cos, sin). */
+typedef struct {
+  const void* x; void* y;     /* bf16 [M, ld*]; y may alias x */
+  const float* weight;        /* [d] */
+  const float* rope;          /* or NULL */
+  int M, d, ldx, ldy, head_dim, tokens_per_batch;
+  float eps;
+} v3a_rmsnorm_rope_args;
+int v3a_rmsnorm_rope(const v3a_rmsnorm_rope_args* args, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

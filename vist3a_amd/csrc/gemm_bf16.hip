@@ -1,0 +1,318 @@
+// bf16 NT GEMM for gfx950:  C[M,N] = epilogue(A[M,K] . B[N,K]^T), fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16.  Replaces nn.Linear under autocast on the DiT / ViT rows of SURVEY.md §8
+// (A3,A4,A6,A7,A8,A9,R4,R6,R7,R9).
+//
+// Structure (one workgroup = one BMxBN output tile, 64-wide waves in a WMxWN grid):
+//   * K is walked in BK=64 slabs.  A and B slabs are copied global->LDS with 16-byte LDS-DMA
+//     (global_load_lds_dwordx4): one wave instruction moves 8 rows x 128 B.  The LDS image is
+//     lane-linear, so the bank swizzle  chunk' = chunk ^ ((row>>1)&7)  is applied to the per-lane
+//     SOURCE address and again on the fragment read (both sides or neither).
+//   * two LDS stages; the DMA for slab t+1 is issued before the MFMAs of slab t and retired by a
+//     counted wait + one s_barrier per slab.
+//   * MFMA operands are issued as (B-fragment, A-fragment) so each lane ends up with 4 CONSECUTIVE
+//     output columns per accumulator quad (D^T orientation): the epilogue packs them to bf16, parks
+//     the wave's tile in LDS, and re-reads whole rows so that bias / activation / gate / residual and
+//     the global stores are all 16-byte coalesced.
+//   * workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous run of tiles.
+#include "common.h"
+#include "../../include/vist3a_hip.h"
+
+namespace {
+
+struct GemmP {
+  const char* A;
+  const char* B;
+  char* C;
+  const float* bias;
+  const char* res;
+  const float* scale;
+  int M, N, K;
+  int lda, ldb, ldc, ldr;  // in elements
+  int rpb, sstride;
+  int act, flags;
+};
+
+template <int BM, int BN, int WM, int WN>
+struct TileCfg {
+  static constexpr int NW = WM * WN;
+  static constexpr int NTHR = NW * 64;
+  static constexpr int WTM = BM / WM, WTN = BN / WN;
+  static constexpr int MT = WTM / 32, NTL = WTN / 32;
+  static constexpr int ROWS = BM + BN;
+  static constexpr int STAGE = ROWS * 128;
+  static constexpr int NL = ROWS / 8 / NW;
+  static constexpr int PITCH = WTN * 2 + 8;
+  static constexpr int EPI_BYTES = NW * WTM * PITCH;
+  static constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  static_assert(ROWS % (8 * NW) == 0, "staging rows must divide evenly over waves");
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
+  static_assert(BM % 32 == 0, "swizzle assumes B rows start at a multiple of 32");
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
+  using T = TileCfg<BM, BN, WM, WN>;
+  constexpr int NW = T::NW, MT = T::MT, NTL = T::NTL, NL = T::NL, STAGE = T::STAGE;
+  constexpr int WTM = T::WTM, WTN = T::WTN, PITCH = T::PITCH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
+  const int t = xcd_remap(blockIdx.x, tilesM * tilesN);
+  const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
+
+  // ---- per-lane staging sources (advance by 128 B per K slab) ----
+  const char* gp[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    const int g = j * NW + wave;  // wave-uniform 8-row group
+    const int R = g * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((R >> 1) & 7);
+    if (g * 8 < BM) {
+      int row = m0 + R;
+      row = row < p.M ? row : p.M - 1;
+      gp[j] = p.A + ((size_t)row * p.lda) * 2 + c * 16;
+    } else {
+      int row = n0 + (R - BM);
+      row = row < p.N ? row : p.N - 1;
+      gp[j] = p.B + ((size_t)row * p.ldb) * 2 + c * 16;
+    }
+  }
+  auto stage = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      glds16(gp[j], smem + s * STAGE + (j * NW + wave) * 1024);
+      gp[j] += 128;
+    }
+  };
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int sw = (lane >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + hi) ^ sw) << 4);
+  const int aoff = (wm * WTM) * 128, boff = (BM + wn * WTN) * 128;
+
+  const int nk = p.K / 64;
+  stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1);
+    const char* sA = smem + cur * STAGE + aoff;
+    const char* sB = smem + cur * STAGE + boff;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 a[MT], b[NTL];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *(const bf16x8*)(sA + i * 4096 + koff[ks]);
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) b[j] = *(const bf16x8*)(sB + j * 4096 + koff[ks]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue phase 1: acc + bias -> bf16 -> this wave's private LDS region ----
+  char* reg = smem + wave * (WTM * PITCH);
+  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+  const bool bias_row = (p.flags & V3A_GEMM_BIAS_ROW) != 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int ml = i * 32 + l31;
+    float brow = 0.f;
+    if (p.bias && bias_row) {
+      int m = mw + ml;
+      brow = p.bias[m < p.M ? m : p.M - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = j * 32 + g * 8 + hi * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+        if (p.bias) {
+          if (bias_row) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += brow;
+          } else {
+            const int n = nw + nl;
+            if (n + 3 < p.N) {
+              const f32x4 bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bv[e];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) v[e] += p.bias[n + e];
+            }
+          }
+        }
+        u32x2 pk;
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)(reg + ml * PITCH + nl * 2) = pk;
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- epilogue phase 2: whole-row re-read, fused elementwise, 16-byte coalesced stores ----
+  constexpr int CH = WTN / 8;
+  constexpr int ITERS = WTM * CH / 64;
+  static_assert((WTM * CH) % 64 == 0, "epilogue chunking");
+  const int act = p.act, flags = p.flags;
+#pragma unroll 2
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = it * 64 + lane;
+    const int ml = idx / CH, ch = idx % CH;
+    const int m = mw + ml, n = nw + ch * 8;
+    const u32x2 lo = *(const u32x2*)(reg + ml * PITCH + ch * 16);
+    const u32x2 hi2 = *(const u32x2*)(reg + ml * PITCH + ch * 16 + 8);
+    if (m >= p.M || n >= p.N) continue;
+    u32x4 raw;
+    raw[0] = lo[0]; raw[1] = lo[1]; raw[2] = hi2[0]; raw[3] = hi2[1];
+    float v[8];
+    unpack_bf16x8(raw, v);
+    if (act != V3A_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e];
+        if (act == V3A_ACT_GELU_TANH) x = gelu_tanh(x);
+        else if (act == V3A_ACT_GELU_ERF) x = gelu_erf(x);
+        else if (act == V3A_ACT_SILU) x = silu(x);
+        else x = fmaxf(x, 0.f);
+        v[e] = round_bf16(x);
+      }
+    }
+    if (p.scale) {
+      const float* sp = p.scale + ((flags & V3A_GEMM_SCALE_PER_BATCH) ? (size_t)(m / p.rpb) * p.sstride : 0) + n;
+      const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] *= s0[e]; v[4 + e] *= s1[e]; }
+      if (flags & V3A_GEMM_ROUND_AFTER_SCALE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e]);
+      }
+    }
+    if (p.res) {
+      if (flags & V3A_GEMM_RES_F32) {
+        const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
+        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+      } else {
+        const u32x4 rr = *(const u32x4*)(p.res + ((size_t)m * p.ldr + n) * 2);
+        float rf[8];
+        unpack_bf16x8(rr, rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+      }
+    }
+    if (flags & V3A_GEMM_OUT_F32) {
+      float* cp = (float*)p.C + (size_t)m * p.ldc + n;
+      f32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
+      *(f32x4*)cp = o0;
+      *(f32x4*)(cp + 4) = o1;
+    } else {
+      *(u32x4*)(p.C + ((size_t)m * p.ldc + n) * 2) = pack_bf16x8(v);
+    }
+  }
+}
+
+typedef void (*gemm_fn)(const GemmP);
+struct TileEntry {
+  const char* name;
+  int BM, BN, nthr, lds;
+  gemm_fn fn;
+};
+
+#define TILE_ENTRY(BM, BN, WM, WN)                                                   \
+  { #BM "x" #BN "_w" #WM "x" #WN, BM, BN, TileCfg<BM, BN, WM, WN>::NTHR,            \
+    TileCfg<BM, BN, WM, WN>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN> }
+
+const TileEntry kTiles[] = {
+    TILE_ENTRY(256, 192, 4, 2),  // 0: N % 192 == 0 shapes (d=1536): 8192x1536 -> exactly 256 tiles
+    TILE_ENTRY(192, 256, 2, 4),  // 1: transposed role of 0 (V^T = Wv . X^T)
+    TILE_ENTRY(256, 256, 2, 4),  // 2
+    TILE_ENTRY(128, 256, 2, 4),  // 3
+    TILE_ENTRY(256, 128, 4, 2),  // 4
+    TILE_ENTRY(128, 128, 2, 2),  // 5: small / ragged problems, 2 workgroups per CU
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+bool g_attr_set[kNumTiles] = {};
+
+int pick_tile(int M, int N) {
+  // minimise (#rounds over 256 CUs) x (tile area incl. padding waste); prefer bigger tiles on ties.
+  double best = 1e30;
+  int bi = kNumTiles - 1;
+  for (int i = 0; i < kNumTiles; ++i) {
+    const TileEntry& e = kTiles[i];
+    long tm = (M + e.BM - 1) / e.BM, tn = (N + e.BN - 1) / e.BN;
+    long tiles = tm * tn;
+    int per_cu = (e.lds <= 80 * 1024) ? 2 : 1;
+    long slots = 256L * per_cu;
+    long rounds = (tiles + slots - 1) / slots;
+    // co-resident small tiles run ~concurrently: cost per round ~ per_cu tiles' area, small efficiency bonus for large tiles
+    double eff = (e.BM * e.BN >= 256 * 192) ? 1.0 : (e.BM * e.BN >= 128 * 256 ? 0.9 : 0.8);
+    double cost = (double)rounds * per_cu * e.BM * e.BN / eff;
+    if (cost < best - 1e-9) { best = cost; bi = i; }
+  }
+  return bi;
+}
+
+}  // namespace
+
+extern "C" int v3a_gemm_num_tiles(void) { return kNumTiles; }
+extern "C" const char* v3a_gemm_tile_name(int t) { return (t >= 0 && t < kNumTiles) ? kTiles[t].name : ""; }
+
+extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
+  if (!a || !a->A || !a->B || !a->C) return V3A_ERR_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return V3A_ERR_SHAPE;
+  if (a->K % 64 || a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->N % 8) return V3A_ERR_SHAPE;
+  if (a->residual && (a->ldr % 8)) return V3A_ERR_SHAPE;
+  if ((a->flags & V3A_GEMM_SCALE_PER_BATCH) && a->scale && a->rows_per_batch <= 0) return V3A_ERR_ARG;
+  if (a->flags & V3A_GEMM_NO_ROUND_ACC) return V3A_ERR_ARG;  // not implemented: accumulators are parked as bf16
+  int ti = a->tile;
+  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(a->M, a->N);
+  const TileEntry& e = kTiles[ti];
+  GemmP p;
+  p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C;
+  p.bias = a->bias; p.res = (const char*)a->residual; p.scale = a->scale;
+  p.M = a->M; p.N = a->N; p.K = a->K;
+  p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr;
+  p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : 1; p.sstride = a->scale_stride;
+  p.act = a->act; p.flags = a->flags;
+  if (!g_attr_set[ti]) {
+    if (hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, e.lds) != hipSuccess)
+      return V3A_ERR_LAUNCH;
+    g_attr_set[ti] = true;
+  }
+  const long tiles = (long)((a->M + e.BM - 1) / e.BM) * ((a->N + e.BN - 1) / e.BN);
+  hipLaunchKernelGGL(e.fn, dim3((unsigned)tiles), dim3(e.nthr), e.lds, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}

@@ -1,0 +1,116 @@
+"""ctypes binding of libvist3a_hip.so (C ABI declared in include/vist3a_hip.h).
+
+The product path has no fallback: if the shared object is missing or fails to load, every op raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libvist3a_hip.so"
+
+V3A_OK = 0
+ERRORS = {-1: "V3A_ERR_ARG", -2: "V3A_ERR_SHAPE", -3: "V3A_ERR_LAUNCH"}
+
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4
+GEMM_BIAS_ROW = 1 << 0
+GEMM_SCALE_PER_BATCH = 1 << 1
+GEMM_ROUND_AFTER_SCALE = 1 << 2
+GEMM_RES_F32 = 1 << 3
+GEMM_OUT_F32 = 1 << 4
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("bias", C.c_void_p), ("residual", C.c_void_p), ("scale", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
+        ("rows_per_batch", C.c_int), ("scale_stride", C.c_int),
+        ("act", C.c_int), ("flags", C.c_int), ("tile", C.c_int),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p),
+        ("q_batch_stride", C.c_long), ("k_batch_stride", C.c_long),
+        ("vt_batch_stride", C.c_long), ("o_batch_stride", C.c_long),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int),
+        ("scale", C.c_float),
+    ]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p),
+        ("weight", C.c_void_p), ("bias", C.c_void_p),
+        ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("M", C.c_int), ("d", C.c_int), ("ldx", C.c_int), ("ldy", C.c_int),
+        ("rows_per_batch", C.c_int), ("mod_stride", C.c_int),
+        ("eps", C.c_float),
+        ("x_is_f32", C.c_int), ("y_is_f32", C.c_int),
+    ]
+
+
+class RmsNormRopeArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p),
+        ("weight", C.c_void_p), ("rope", C.c_void_p),
+        ("M", C.c_int), ("d", C.c_int), ("ldx", C.c_int), ("ldy", C.c_int),
+        ("head_dim", C.c_int), ("tokens_per_batch", C.c_int),
+        ("eps", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/vist3a_hip.h declares must be listed here
+SYMBOLS = {
+    "v3a_abi_version": (C.c_int, []),
+    "v3a_build_info": (C.c_char_p, []),
+    "v3a_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "v3a_gemm_num_tiles": (C.c_int, []),
+    "v3a_gemm_tile_name": (C.c_char_p, [C.c_int]),
+    "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    "v3a_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
+    "v3a_rmsnorm_rope": (C.c_int, [C.POINTER(RmsNormRopeArgs), C.c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load(path: os.PathLike | None = None) -> C.CDLL:
+    """Load (once) and type the shared library.  Raises HipLibraryError when it is absent — there is no
+    CPU or eager-PyTorch fallback on the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise HipLibraryError(
+            f"{p} not found: build it with `python -m vist3a_amd.build` (hipcc, gfx950). "
+            "The VIST3A MI355X path has no fallback implementation."
+        )
+    try:
+        lib = C.CDLL(str(p))
+    except OSError as e:  # pragma: no cover - depends on the ROCm runtime being present
+        raise HipLibraryError(f"failed to load {p}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{p} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != V3A_OK:
+        raise RuntimeError(f"{what} failed: {ERRORS.get(rc, rc)}")

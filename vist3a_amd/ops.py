@@ -1,0 +1,165 @@
+"""Thin torch-tensor wrappers over the C ABI (include/vist3a_hip.h).
+
+PyTorch supplies device memory and the current HIP stream only; all arithmetic happens inside
+libvist3a_hip.so.  Every wrapper validates dtype/device/contiguity and raises on any non-zero return."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk2d(t: torch.Tensor, name: str, dtypes) -> None:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype not in dtypes:
+        raise TypeError(f"{name} has dtype {t.dtype}, expected one of {dtypes}")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name} must be 2-D with a contiguous last dim, got shape {tuple(t.shape)} stride {t.stride()}")
+
+
+def gemm(
+    a: torch.Tensor,
+    w: torch.Tensor,
+    bias: Optional[torch.Tensor] = None,
+    *,
+    out: Optional[torch.Tensor] = None,
+    act: int = L.ACT_NONE,
+    residual: Optional[torch.Tensor] = None,
+    scale: Optional[torch.Tensor] = None,
+    rows_per_batch: int = 0,
+    round_after_scale: bool = False,
+    out_f32: bool = False,
+    bias_row: bool = False,
+    tile: int = -1,
+) -> torch.Tensor:
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T); see v3a_gemm_bf16_nt for the epilogue order.
+
+    scale: f32 [N] (LayerScale) or [nbatch, N] together with rows_per_batch (AdaLN gate)."""
+    _chk2d(a, "a", (bf16,))
+    _chk2d(w, "w", (bf16,))
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise ValueError(f"K mismatch: a {tuple(a.shape)} vs w {tuple(w.shape)}")
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
+    _chk2d(out, "out", (f32,) if out_f32 else (bf16,))
+    flags = 0
+    if bias is not None:
+        if bias.dtype != f32 or not bias.is_contiguous() or bias.numel() != (M if bias_row else N):
+            raise ValueError("bias must be contiguous f32 of length N (or M with bias_row)")
+        if bias_row:
+            flags |= L.GEMM_BIAS_ROW
+    sstride = 0
+    if scale is not None:
+        if scale.dtype != f32 or scale.stride(-1) != 1:
+            raise ValueError("scale must be f32 with contiguous last dim")
+        if scale.dim() == 2:
+            if rows_per_batch <= 0:
+                raise ValueError("2-D scale needs rows_per_batch")
+            flags |= L.GEMM_SCALE_PER_BATCH
+            sstride = scale.stride(0)
+        if round_after_scale:
+            flags |= L.GEMM_ROUND_AFTER_SCALE
+    ldr = 0
+    if residual is not None:
+        _chk2d(residual, "residual", (bf16, f32))
+        if residual.shape != (M, N):
+            raise ValueError("residual shape mismatch")
+        if residual.dtype == f32:
+            flags |= L.GEMM_RES_F32
+        ldr = residual.stride(0)
+    if out_f32:
+        flags |= L.GEMM_OUT_F32
+    args = L.GemmArgs(
+        _ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(scale),
+        M, N, K, a.stride(0), w.stride(0), out.stride(0), ldr,
+        rows_per_batch, sstride, act, flags, tile,
+    )
+    L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")
+    return out
+
+
+def attention(
+    q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *,
+    B: int, H: int, Nq: int, Nk: int, D: int,
+    q_batch_stride: int, k_batch_stride: int, vt_batch_stride: int, o_batch_stride: int,
+    scale: Optional[float] = None,
+) -> torch.Tensor:
+    """q,k,out: 2-D views [B*N, >=H*D] (row stride = their stride(0)); vt: 2-D [H*D, >=B*vt_batch_stride]."""
+    for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (out, "out")):
+        _chk2d(t, n, (bf16,))
+    args = L.AttnArgs(
+        _ptr(q), _ptr(k), _ptr(vt), _ptr(out),
+        q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride,
+        q.stride(0), k.stride(0), vt.stride(0), out.stride(0),
+        B, H, Nq, Nk, D, float(scale if scale is not None else D ** -0.5),
+    )
+    L.check(L.load().v3a_attention_fwd_bf16(C.byref(args), _stream()), "v3a_attention_fwd_bf16")
+    return out
+
+
+def layernorm(
+    x: torch.Tensor, *, out: Optional[torch.Tensor] = None,
+    weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+    scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+    rows_per_batch: int = 0, eps: float = 1e-6, out_dtype: torch.dtype = bf16,
+) -> torch.Tensor:
+    _chk2d(x, "x", (bf16, f32))
+    M, d = x.shape
+    if out is None:
+        out = torch.empty((M, d), device=x.device, dtype=out_dtype)
+    _chk2d(out, "out", (bf16, f32))
+    mstride = 0
+    if scale is not None:
+        if scale.dtype != f32 or shift is None or shift.dtype != f32 or scale.dim() != 2 or shift.dim() != 2:
+            raise ValueError("scale/shift must both be 2-D f32")
+        if scale.stride(0) != shift.stride(0) or scale.stride(1) != 1 or shift.stride(1) != 1:
+            raise ValueError("scale/shift must share a row stride and be contiguous in the last dim")
+        mstride = scale.stride(0)
+    for t in (weight, bias):
+        if t is not None and (t.dtype != f32 or not t.is_contiguous()):
+            raise ValueError("affine weight/bias must be contiguous f32")
+    args = L.LayerNormArgs(
+        _ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(scale), _ptr(shift),
+        M, d, x.stride(0), out.stride(0), rows_per_batch, mstride, eps,
+        int(x.dtype == f32), int(out.dtype == f32),
+    )
+    L.check(L.load().v3a_layernorm(C.byref(args), _stream()), "v3a_layernorm")
+    return out
+
+
+def rmsnorm_rope(
+    x: torch.Tensor, weight: torch.Tensor, *, out: Optional[torch.Tensor] = None,
+    rope: Optional[torch.Tensor] = None, head_dim: int = 0, tokens_per_batch: int = 0, eps: float = 1e-6,
+) -> torch.Tensor:
+    _chk2d(x, "x", (bf16,))
+    M, d = x.shape
+    if out is None:
+        out = torch.empty((M, d), device=x.device, dtype=bf16)
+    _chk2d(out, "out", (bf16,))
+    if weight.dtype != f32 or not weight.is_contiguous() or weight.numel() != d:
+        raise ValueError("weight must be contiguous f32 [d]")
+    if rope is not None and (rope.dtype != f32 or not rope.is_contiguous()):
+        raise ValueError("rope table must be contiguous f32 [tokens, head_dim/2, 2]")
+    args = L.RmsNormRopeArgs(
+        _ptr(x), _ptr(out), _ptr(weight), _ptr(rope), M, d, x.stride(0), out.stride(0),
+        head_dim, tokens_per_batch, eps,
+    )
+    L.check(L.load().v3a_rmsnorm_rope(C.byref(args), _stream()), "v3a_rmsnorm_rope")
+    return out
