@@ -1,0 +1,228 @@
+"""ORACLE (test infrastructure — never imported by the product path).
+
+CPU restatement of the Wan-2.1 DiT forward.  The arithmetic lives in the
+un-vendored wheel `diffusers==0.33.1` (pinned at /root/reference/requirements.txt:20), which is absent from
+/root/reference and from this image, so this file restates the published architecture of that version:
+    WanTransformer3DModel / WanTransformerBlock / WanAttnProcessor2_0 / WanRotaryPosEmbed /
+    WanTimeTextImageEmbedding
+and anchors on the reference's own call sites:
+    /root/reference/inference_t23d.py:94-103   pipe(...) -> transformer(hidden_states, timestep, encoder_hidden_states)
+    /root/reference/train_vdm.py:592-607       transformer(hidden_states=z, timestep=t, encoder_hidden_states=emb, return_dict=False)[0]
+    /root/reference/train_vdm.py:370-379       LoRA target names attn1/attn2.{to_q,to_k,to_v,to_out.0}
+PARITY UNPINNED: the reference holds no tests or golden vectors for this boundary; the
+restatement is guarded by self-consistency known-answer tests in tests/test_oracle_dit.py.
+
+Weights use the diffusers state-dict names (blocks.{i}.attn1.to_q.weight, ...ffn.net.0.proj..., etc.).
+`emulate_bf16=True` rounds at the points CUDA bf16 autocast rounds in the reference (Linear / SDPA outputs,
+type_as(hidden_states)) while accumulating in fp32 — the contract the HIP kernels implement.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class WanDiTConfig:
+    patch_size: tuple = (1, 2, 2)
+    num_attention_heads: int = 12
+    attention_head_dim: int = 128
+    in_channels: int = 16
+    out_channels: int = 16
+    text_dim: int = 4096
+    freq_dim: int = 256
+    ffn_dim: int = 8960
+    num_layers: int = 30
+    eps: float = 1e-6
+    rope_max_seq_len: int = 1024
+
+    @property
+    def dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+
+WAN_1_3B = WanDiTConfig()
+WAN_14B = WanDiTConfig(num_attention_heads=40, ffn_dim=13824, num_layers=40)
+
+
+def _r(x: torch.Tensor, emu: bool) -> torch.Tensor:
+    """bf16 rounding point (no-op in pure fp32 mode)."""
+    return x.to(torch.bfloat16).to(torch.float32) if emu else x
+
+
+def _lin(x, sd, name, emu):
+    w, b = sd[name + ".weight"].float(), sd.get(name + ".bias")
+    if emu:
+        x, w = _r(x, True), _r(w, True)
+    y = F.linear(x, w, None if b is None else b.float())
+    return _r(y, emu)
+
+
+def rope_freqs(cfg: WanDiTConfig) -> torch.Tensor:
+    """WanRotaryPosEmbed.__init__: complex128 table [max_seq_len, head_dim/2]; split t/h/w = 44/42/42 real dims."""
+    hd = cfg.attention_head_dim
+    h_dim = w_dim = 2 * (hd // 6)
+    t_dim = hd - h_dim - w_dim
+    out = []
+    for dim in (t_dim, h_dim, w_dim):
+        inv = 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float64)[: dim // 2] / dim))
+        ang = torch.outer(torch.arange(cfg.rope_max_seq_len, dtype=torch.float64), inv)
+        out.append(torch.polar(torch.ones_like(ang), ang))
+    return torch.cat(out, dim=1)
+
+
+def rope_for_grid(cfg: WanDiTConfig, ppf: int, pph: int, ppw: int) -> torch.Tensor:
+    """WanRotaryPosEmbed.forward: [ppf*pph*ppw, head_dim/2] complex128, token order (f, h, w)."""
+    hd = cfg.attention_head_dim
+    fr = rope_freqs(cfg).split_with_sizes([hd // 2 - 2 * (hd // 6), hd // 6, hd // 6], dim=1)
+    ff = fr[0][:ppf].view(ppf, 1, 1, -1).expand(ppf, pph, ppw, -1)
+    fh = fr[1][:pph].view(1, pph, 1, -1).expand(ppf, pph, ppw, -1)
+    fw = fr[2][:ppw].view(1, 1, ppw, -1).expand(ppf, pph, ppw, -1)
+    return torch.cat([ff, fh, fw], dim=-1).reshape(ppf * pph * ppw, -1)
+
+
+def apply_rope(x: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    """x [B,H,N,hd] real; complex multiply of adjacent pairs in float64 (WanAttnProcessor2_0.apply_rotary_emb)."""
+    xc = torch.view_as_complex(x.to(torch.float64).unflatten(3, (-1, 2)))
+    return torch.view_as_real(xc * freqs[None, None]).flatten(3, 4).to(x.dtype)
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0, max_period=10000)."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    emb = t.float()[:, None] * torch.exp(exponent)[None]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+def rms_norm(x, w, eps):
+    var = x.float().pow(2).mean(-1, keepdim=True)
+    return x.float() * torch.rsqrt(var + eps) * w.float()
+
+
+def attention(q, k, v, heads, emu):
+    B, Nq, d = q.shape
+    hd = d // heads
+    qh = q.view(B, Nq, heads, hd).transpose(1, 2)
+    kh = k.view(B, -1, heads, hd).transpose(1, 2)
+    vh = v.view(B, -1, heads, hd).transpose(1, 2)
+    o = F.scaled_dot_product_attention(_r(qh, emu), _r(kh, emu), _r(vh, emu))
+    return _r(o.transpose(1, 2).reshape(B, Nq, d), emu)
+
+
+def condition_embed(sd, cfg, timestep, text, emu):
+    """WanTimeTextImageEmbedding: returns temb [B,d], timestep_proj [B,6,d], ctx [B,L,d]."""
+    p = "condition_embedder."
+    te = timestep_embedding(timestep, cfg.freq_dim)
+    temb = _lin(F.silu(_lin(te, sd, p + "time_embedder.linear_1", emu)), sd, p + "time_embedder.linear_2", emu)
+    tproj = _lin(_r(F.silu(temb), emu), sd, p + "time_proj", emu).unflatten(1, (6, -1))
+    ctx = _lin(text.float(), sd, p + "text_embedder.linear_1", emu)
+    ctx = _lin(_r(F.gelu(ctx, approximate="tanh"), emu), sd, p + "text_embedder.linear_2", emu)
+    return temb, tproj, ctx
+
+
+def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu):
+    p = f"blocks.{i}."
+    d, H, eps = cfg.dim, cfg.num_attention_heads, cfg.eps
+    mod = sd[p + "scale_shift_table"].float() + tproj.float()  # [B,6,d]
+    shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = mod.chunk(6, dim=1)
+    # 1. self attention
+    n = _r(F.layer_norm(x.float(), (d,), eps=eps) * (1 + scale_msa) + shift_msa, emu)
+    q = _lin(n, sd, p + "attn1.to_q", emu)
+    k = _lin(n, sd, p + "attn1.to_k", emu)
+    v = _lin(n, sd, p + "attn1.to_v", emu)
+    q = rms_norm(q, sd[p + "attn1.norm_q.weight"], eps)
+    k = rms_norm(k, sd[p + "attn1.norm_k.weight"], eps)
+    B, N, _ = q.shape
+    q = apply_rope(q.view(B, N, H, -1).transpose(1, 2), freqs).transpose(1, 2).reshape(B, N, d)
+    k = apply_rope(k.view(B, N, H, -1).transpose(1, 2), freqs).transpose(1, 2).reshape(B, N, d)
+    a = _lin(attention(q, k, v, H, emu), sd, p + "attn1.to_out.0", emu)
+    x = _r(x.float() + a * gate_msa, emu)
+    # 2. cross attention (norm2 has affine, no modulation; no mask over zero-padded text rows)
+    n = _r(F.layer_norm(x.float(), (d,), sd[p + "norm2.weight"].float(), sd[p + "norm2.bias"].float(), eps), emu)
+    q = rms_norm(_lin(n, sd, p + "attn2.to_q", emu), sd[p + "attn2.norm_q.weight"], eps)
+    k = rms_norm(_lin(ctx, sd, p + "attn2.to_k", emu), sd[p + "attn2.norm_k.weight"], eps)
+    v = _lin(ctx, sd, p + "attn2.to_v", emu)
+    a = _lin(attention(q, k, v, H, emu), sd, p + "attn2.to_out.0", emu)
+    x = _r(x + a, emu)
+    # 3. feed forward
+    n = _r(F.layer_norm(x.float(), (d,), eps=eps) * (1 + c_scale) + c_shift, emu)
+    h = _r(F.gelu(_lin(n, sd, p + "ffn.net.0.proj", emu), approximate="tanh"), emu)
+    f = _lin(h, sd, p + "ffn.net.2", emu)
+    x = _r(x.float() + f.float() * c_gate, emu)
+    return x
+
+
+def patchify(cfg, latents):
+    """Conv3d(k=s=patch) as a reshape: [B,C,F,H,W] -> tokens [B, N, C*pt*ph*pw] in (f,h,w) order, channel-major."""
+    B, C, Fr, Hh, Ww = latents.shape
+    pt, ph, pw = cfg.patch_size
+    x = latents.view(B, C, Fr // pt, pt, Hh // ph, ph, Ww // pw, pw)
+    return x.permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, (Fr // pt) * (Hh // ph) * (Ww // pw), C * pt * ph * pw)
+
+
+def unpatchify(cfg, tokens, Fr, Hh, Ww):
+    B = tokens.shape[0]
+    pt, ph, pw = cfg.patch_size
+    x = tokens.reshape(B, Fr // pt, Hh // ph, Ww // pw, pt, ph, pw, -1)
+    x = x.permute(0, 7, 1, 4, 2, 5, 3, 6)
+    return x.flatten(6, 7).flatten(4, 5).flatten(2, 3)
+
+
+def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.Tensor, timestep: torch.Tensor,
+                text: torch.Tensor, emulate_bf16: bool = False, num_layers: int | None = None) -> torch.Tensor:
+    """transformer(hidden_states[B,16,T,H,W], timestep[B], encoder_hidden_states[B,L,4096]) -> [B,16,T,H,W]."""
+    emu = emulate_bf16
+    B, C, Fr, Hh, Ww = latents.shape
+    pt, ph, pw = cfg.patch_size
+    freqs = rope_for_grid(cfg, Fr // pt, Hh // ph, Ww // pw)
+    w = sd["patch_embedding.weight"].float().reshape(cfg.dim, -1)
+    tok = patchify(cfg, latents.float())
+    x = _r(F.linear(_r(tok, emu), _r(w, emu), sd["patch_embedding.bias"].float()), emu)
+    temb, tproj, ctx = condition_embed(sd, cfg, timestep, text, emu)
+    L = cfg.num_layers if num_layers is None else num_layers
+    for i in range(L):
+        x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu)
+    shift, scale = (sd["scale_shift_table"].float() + temb.float().unsqueeze(1)).chunk(2, dim=1)
+    x = _r(F.layer_norm(x.float(), (cfg.dim,), eps=cfg.eps) * (1 + scale) + shift, emu)
+    x = _lin(x, sd, "proj_out", emu)
+    return unpatchify(cfg, x, Fr, Hh, Ww)
+
+
+def make_weights(cfg: WanDiTConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Seeded random weights with the production shapes/names (SURVEY.md §8d synthetic-input spec)."""
+    g = torch.Generator().manual_seed(seed)
+    d, ffn = cfg.dim, cfg.ffn_dim
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, o, i, std=0.02):
+        sd[name + ".weight"] = (torch.randn(o, i, generator=g) * std).to(dtype)
+        sd[name + ".bias"] = (torch.randn(o, generator=g) * 0.02).to(dtype)
+
+    pt, ph, pw = cfg.patch_size
+    sd["patch_embedding.weight"] = (torch.randn(d, cfg.in_channels, pt, ph, pw, generator=g) * 0.05).to(dtype)
+    sd["patch_embedding.bias"] = (torch.randn(d, generator=g) * 0.02).to(dtype)
+    lin("condition_embedder.time_embedder.linear_1", d, cfg.freq_dim)
+    lin("condition_embedder.time_embedder.linear_2", d, d)
+    lin("condition_embedder.time_proj", 6 * d, d)
+    lin("condition_embedder.text_embedder.linear_1", d, cfg.text_dim)
+    lin("condition_embedder.text_embedder.linear_2", d, d)
+    for i in range(cfg.num_layers):
+        p = f"blocks.{i}."
+        sd[p + "scale_shift_table"] = (torch.randn(1, 6, d, generator=g) / math.sqrt(d)).to(dtype)
+        for a in ("attn1", "attn2"):
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                lin(p + f"{a}.{n}", d, d)
+            sd[p + f"{a}.norm_q.weight"] = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype)
+            sd[p + f"{a}.norm_k.weight"] = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype)
+        sd[p + "norm2.weight"] = (1 + 0.1 * torch.randn(d, generator=g)).to(dtype)
+        sd[p + "norm2.bias"] = (0.05 * torch.randn(d, generator=g)).to(dtype)
+        lin(p + "ffn.net.0.proj", ffn, d)
+        lin(p + "ffn.net.2", d, ffn)
+    sd["scale_shift_table"] = (torch.randn(1, 2, d, generator=g) / math.sqrt(d)).to(dtype)
+    lin("proj_out", cfg.out_channels * pt * ph * pw, d)
+    return sd

@@ -1,0 +1,65 @@
+"""UniPC host logic vs the oracle restatement + known-answer tests (parity unpinned by the reference)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.unipc import OracleUniPC
+from vist3a_amd.wan.scheduler import UniPCMultistepScheduler
+
+
+def test_sigma_table_kat():
+    s = UniPCMultistepScheduler(flow_shift=5.0)
+    s.set_timesteps(50)
+    assert len(s.timesteps) == 50 and len(s.sigmas) == 51
+    # sigma_0 = shift*s/(1+(shift-1)s) at s = 1-1/1000
+    s0 = 5.0 * 0.999 / (1 + 4 * 0.999)
+    assert abs(s.sigmas[0].item() - s0) < 1e-6
+    assert s.timesteps[0].item() == int(s0 * 1000)
+    assert s.sigmas[-1].item() == 0.0
+    assert torch.all(s.sigmas[:-1] > s.sigmas[1:])
+    assert s.timesteps.dtype == torch.int64
+    s.set_timesteps(10)
+    assert len(s.timesteps) == 10
+
+
+@pytest.mark.parametrize("steps,shift", [(10, 5.0), (50, 5.0), (7, 3.0)])
+def test_matches_oracle(steps, shift):
+    torch.manual_seed(0)
+    a = UniPCMultistepScheduler(flow_shift=shift)
+    a.set_timesteps(steps)
+    o = OracleUniPC(flow_shift=shift)
+    o.set_timesteps(steps)
+    assert torch.equal(a.timesteps, o.timesteps)
+    assert torch.equal(a.sigmas, o.sigmas)
+    xa = xo = torch.randn(1, 4, 2, 3, 3)
+    for i, t in enumerate(a.timesteps):
+        v = torch.randn(1, 4, 2, 3, 3).to(torch.bfloat16)
+        xa = a.step(v, t, xa)[0]
+        xo = o.step(v, xo)
+        assert xa.dtype == torch.float32
+        assert torch.allclose(xa, xo, rtol=2e-5, atol=2e-5), (i, (xa - xo).abs().max())
+    assert torch.isfinite(xa).all()
+
+
+def test_terminal_step_returns_x0():
+    """sigma_last = 0: the final predictor step must land exactly on the last x0 prediction."""
+    a = UniPCMultistepScheduler(flow_shift=5.0)
+    a.set_timesteps(4)
+    x = torch.randn(1, 2, 1, 2, 2)
+    for t in a.timesteps:
+        v = torch.randn_like(x)
+        x = a.step(v, t, x)[0]
+    assert torch.allclose(x, a.model_outputs[-1], atol=1e-6)
+
+
+def test_first_step_closed_form():
+    """order-1 UniP == exponential-integrator DDIM step: x_t = (s_t/s_0) x - a_t (e^{-h}-1) x0."""
+    a = UniPCMultistepScheduler(flow_shift=5.0)
+    a.set_timesteps(10)
+    x, v = torch.randn(1, 2, 1, 2, 2), torch.randn(1, 2, 1, 2, 2)
+    s0, s1 = a.sigmas[0].double().item(), a.sigmas[1].double().item()
+    x0 = x - s0 * v
+    h = (np.log(1 - s1) - np.log(s1)) - (np.log(1 - s0) - np.log(s0))
+    want = (s1 / s0) * x - (1 - s1) * np.expm1(-h) * x0
+    got = a.step(v, a.timesteps[0], x)[0]
+    assert torch.allclose(got, want.float(), rtol=1e-4, atol=1e-5)
