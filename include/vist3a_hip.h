@@ -69,6 +69,33 @@ int v3a_gemm_num_tiles(void);
 const char* v3a_gemm_tile_name(int tile);
 
 /* ------------------------------------------------------------------------------------------------
+ * Convolution (1-D/2-D/3-D, stride, zero or replicate padding, causal-in-time, optional fused nearest-exact 2x
+ * spatial upsample of the input) as an implicit GEMM on the same MFMA main loop and epilogue as v3a_gemm_bf16_nt.
+ * replaces nn.Conv3d / nn.Conv2d at
+ *   /root/reference/utils/wan_utils.py:96-147 (WanCausalConv3d), :202-330 (WanResample upsample + Conv2d, time_conv)
+ *   /root/reference/models/stitching_layer_builder.py:32-42 (stitching Conv3d, padding_mode="replicate")
+ *   /root/reference/third_party_model/anysplat/src/model/encoder/vggt/heads/dpt_head.py (DPT convs)
+ * Activations are CHANNELS-LAST: x[T][H][W][Cin] bf16, y[oT*oH*oW][ldy] (first Cout columns written).
+ * Weights are pre-packed  w[Cout][Kpad],  k = ((dt*kH + dh)*kW + dw)*Cin + c, zero padded to Kpad % 64 == 0.
+ * ktab[Kpad/8] describes each 8-channel K chunk:  c | dw<<16 | dh<<20 | dt<<24 | 1<<31 (0 for padding chunks).
+ * Tap (dt,dh,dw) of output (t,h,w) reads input (t*sT+dt-pT, h*sH+dh-pH, w*sW+dw-pW); out-of-range taps read zero
+ * (or the clamped coordinate when `replicate`).  With ups2 the (H,W) coordinates address the 2x upsampled image.
+ * Epilogue = the GEMM epilogue (bias per Cout, act, scale per Cout, residual [M][ldr], bf16/f32 out).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; const void* w; const int* ktab; void* y;
+  const float* bias; const void* residual; const float* scale;
+  int T, H, W, Cin;
+  int oT, oH, oW, Cout, Kpad;
+  int sT, sH, sW;
+  int pT, pH, pW;
+  int ups2, replicate;
+  int ldy, ldr;
+  int act, flags, tile;
+} v3a_conv_args;
+int v3a_conv_bf16(const v3a_conv_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Flash attention forward (non-causal, no mask, no dropout), bf16 in/out, fp32 softmax.
  * replaces F.scaled_dot_product_attention at
  *   diffusers==0.33.1 WanAttnProcessor2_0 (DiT self/cross attention; call site inference_t23d.py:94-103)

@@ -198,6 +198,58 @@ def bench_attn():
             log(test="attn_bench", impl="torch_sdpa", error=str(e)[:200])
 
 
+def check_conv():
+    g = torch.Generator(device=dev).manual_seed(9)
+    F = torch.nn.functional
+    cases = [
+        # name, Cin, Cout, k, T,H,W, stride, pad(leading T,H,W), causal, ups2, replicate
+        ("causal3x3x3_96", 96, 96, (3, 3, 3), 5, 24, 20, (1, 1, 1), (2, 1, 1), True, False, False),
+        ("causal3x3x3_384_192", 384, 192, (3, 3, 3), 3, 16, 16, (1, 1, 1), (2, 1, 1), True, False, False),
+        ("conv1x1_192_384", 192, 384, (1, 1, 1), 2, 16, 16, (1, 1, 1), (0, 0, 0), False, False, False),
+        ("ups_conv3x3_192_96", 192, 96, (1, 3, 3), 3, 16, 12, (1, 1, 1), (0, 1, 1), False, True, False),
+        ("timeconv_384_768", 384, 768, (3, 1, 1), 4, 8, 8, (1, 1, 1), (2, 0, 0), True, False, False),
+        ("stitch_16_1024", 16, 1024, (5, 3, 3), 13, 16, 16, (1, 2, 2), (2, 1, 1), False, False, True),
+        ("conv7x7_3_128", 3, 128, (1, 7, 7), 2, 28, 28, (1, 1, 1), (0, 3, 3), False, False, False),
+        ("conv3x3_96_3", 96, 3, (3, 3, 3), 3, 32, 32, (1, 1, 1), (2, 1, 1), True, False, False),
+        ("conv3x3s2_256", 256, 256, (1, 3, 3), 2, 32, 32, (1, 2, 2), (0, 1, 1), False, False, False),
+    ]
+    for (name, Cin, Cout, k, T, H, W, st, pd, causal, ups2, repl) in cases:
+        w = torch.randn(Cout, Cin, *k, device=dev, generator=g) / math.sqrt(Cin * k[0] * k[1] * k[2])
+        b = torch.randn(Cout, device=dev, generator=g)
+        x = torch.randn(1, Cin, T, H, W, device=dev, generator=g).to(bf16)
+        cw = ops.ConvWeight(w.to(bf16), b)
+        xcl = torch.zeros(T, H, W, cw.CinP, device=dev, dtype=bf16)
+        xcl[..., :Cin] = x[0].permute(1, 2, 3, 0)
+        xin = x.float()
+        if ups2:
+            xin = F.interpolate(xin.transpose(1, 2).reshape(T, Cin, H, W), scale_factor=2.0, mode="nearest-exact").view(1, T, Cin, 2 * H, 2 * W).transpose(1, 2)
+        mode = "replicate" if repl else "constant"
+        if causal:
+            xp = F.pad(xin, (pd[2], pd[2], pd[1], pd[1], pd[0], 0), mode=mode)
+        else:
+            xp = F.pad(xin, (pd[2], pd[2], pd[1], pd[1], pd[0], pd[0]), mode=mode)
+        ref = F.conv3d(xp, w.to(bf16).float(), b, stride=st)
+        res = torch.randn(ref.shape[2], ref.shape[3], ref.shape[4], cw.CoutP, device=dev, generator=g).to(bf16)
+        y = ops.conv(xcl, cw, stride=st, pad=pd, ups2=ups2, replicate=repl, residual=res)
+        torch.cuda.synchronize()
+        refcl = (ref[0].permute(1, 2, 3, 0).to(bf16).float() + res[..., :Cout].float()).to(bf16)
+        r, mx = relerr(y[..., :Cout], refcl)
+        ok = bool(r < 4e-3 and tuple(y.shape[:3]) == tuple(ref.shape[2:]))
+        if cw.CoutP != Cout:
+            ok = ok and bool((y[..., Cout:].float() - res[..., Cout:].float()).abs().max() == 0)
+        log(test="conv", name=name, oshape=list(y.shape), rel=r, maxabs=mx, ok=ok)
+    # throughput at the VAE's dominant shapes
+    for (Cin, Cout, T, H, W) in [(96, 96, 13, 512, 512), (192, 192, 13, 256, 256), (384, 384, 7, 128, 128)]:
+        w = torch.randn(Cout, Cin, 3, 3, 3, device=dev, generator=g) / math.sqrt(Cin * 27)
+        cw = ops.ConvWeight(w.to(bf16), torch.zeros(Cout, device=dev))
+        x = torch.randn(T, H, W, Cin, device=dev, generator=g).to(bf16)
+        out = torch.empty(T, H, W, Cout, device=dev, dtype=bf16)
+        fl = 2.0 * T * H * W * Cout * Cin * 27
+        for tile in [-1, 0, 2, 3, 4, 5]:
+            t = timeit(lambda: ops.conv(x, cw, out=out, pad=(2, 1, 1), tile=tile), iters=5, warm=1)
+            log(test="conv_bench", Cin=Cin, Cout=Cout, T=T, H=H, W=W, tile=tile, ms=t * 1e3, tflops=fl / t / 1e12)
+
+
 def check_norms():
     g = torch.Generator(device=dev).manual_seed(4)
     for (M, d, rpb) in [(8192, 1536, 4096), (1029 * 3, 1024, 0), (100, 2048, 50), (64, 5120, 32), (77, 64, 0)]:

@@ -30,7 +30,17 @@ struct GemmP {
   int lda, ldb, ldc, ldr;  // in elements
   int rpb, sstride;
   int act, flags;
+  // implicit-GEMM convolution (CONV instantiations only): A is a channels-last activation [T][H][W][Cin]
+  const int* ktab;        // one packed entry per 8-channel K chunk: cin | dw<<16 | dh<<20 | dt<<24 | valid<<31
+  int cT, cH, cW, cCin;   // input extent
+  int oH, oW;             // output extent (M = oT*oH*oW)
+  int sT, sH, sW;         // stride
+  int pT, pH, pW;         // leading pad (trailing implied by the output extent)
+  int ups;                // 1: taps address a nearest-exact 2x (H,W) upsample of the stored input
+  int replicate;          // 1: clamp out-of-range taps (padding_mode="replicate"), 0: zero
 };
+
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 template <int BM, int BN, int WM, int WN>
 struct TileCfg {
@@ -47,9 +57,10 @@ struct TileCfg {
   static_assert(ROWS % (8 * NW) == 0, "staging rows must divide evenly over waves");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(BM % 32 == 0, "swizzle assumes B rows start at a multiple of 32");
+  static_assert((BM / 8) % NW == 0, "A/B staging split must fall on an instruction boundary");
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
   using T = TileCfg<BM, BN, WM, WN>;
   constexpr int NW = T::NW, MT = T::MT, NTL = T::NTL, NL = T::NL, STAGE = T::STAGE;
@@ -67,7 +78,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
   const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
 
   // ---- per-lane staging sources (advance by 128 B per K slab) ----
+  constexpr int NLA = (BM / 8 + NW - 1) / NW;  // staging instructions of this wave that can fall in the A tile
   const char* gp[NL];
+  int cvt[CONV ? NLA : 1], cvh[CONV ? NLA : 1], cvw[CONV ? NLA : 1], cvc[CONV ? NLA : 1];
+  int* ktl = (int*)(smem + T::LDS_BYTES);  // CONV: K-chunk table copied behind the tile ring
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
     const int g = j * NW + wave;  // wave-uniform 8-row group
@@ -76,19 +90,56 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
     if (g * 8 < BM) {
       int row = m0 + R;
       row = row < p.M ? row : p.M - 1;
-      gp[j] = p.A + ((size_t)row * p.lda) * 2 + c * 16;
+      if constexpr (CONV) {
+        if (j < NLA) {
+          const int ohw = p.oH * p.oW;
+          const int t = row / ohw, rem = row - t * ohw;
+          const int h = rem / p.oW;
+          cvt[j] = t * p.sT - p.pT; cvh[j] = h * p.sH - p.pH; cvw[j] = (rem - h * p.oW) * p.sW - p.pW;
+          cvc[j] = c;
+        }
+        gp[j] = p.A;
+      } else {
+        gp[j] = p.A + ((size_t)row * p.lda) * 2 + c * 16;
+      }
     } else {
       int row = n0 + (R - BM);
       row = row < p.N ? row : p.N - 1;
       gp[j] = p.B + ((size_t)row * p.ldb) * 2 + c * 16;
     }
   }
+  if constexpr (CONV) {
+    for (int i = tid; i < p.K / 8; i += T::NTHR) ktl[i] = p.ktab[i];
+    __syncthreads();
+  }
+  int kslab = 0;
   auto stage = [&](int s) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
-      glds16(gp[j], smem + s * STAGE + (j * NW + wave) * 1024);
+      const int g = j * NW + wave;
+      if constexpr (CONV) {
+        if (j < NLA) {  // (BM/8) % NW == 0: instruction j < NLA is an A-tile instruction for every wave
+          const int e = ktl[kslab * 8 + cvc[j]];
+          int tt = cvt[j] + ((e >> 24) & 15), hh = cvh[j] + ((e >> 20) & 15), ww = cvw[j] + ((e >> 16) & 15);
+          const int eH = p.ups ? p.cH * 2 : p.cH, eW = p.ups ? p.cW * 2 : p.cW;
+          bool ok = e < 0;  // bit 31 = valid chunk
+          if (p.replicate) {
+            tt = tt < 0 ? 0 : (tt >= p.cT ? p.cT - 1 : tt);
+            hh = hh < 0 ? 0 : (hh >= eH ? eH - 1 : hh);
+            ww = ww < 0 ? 0 : (ww >= eW ? eW - 1 : ww);
+          } else {
+            ok = ok && tt >= 0 && tt < p.cT && hh >= 0 && hh < eH && ww >= 0 && ww < eW;
+          }
+          if (p.ups) { hh >>= 1; ww >>= 1; }
+          const char* src = p.A + (((size_t)(tt * p.cH + hh) * p.cW + ww) * p.cCin + (e & 0xffff)) * 2;
+          glds16(ok ? src : (const char*)&g_zero16, smem + s * STAGE + g * 1024);
+          continue;
+        }
+      }
+      glds16(gp[j], smem + s * STAGE + g * 1024);
       gp[j] += 128;
     }
+    ++kslab;
   };
 
   f32x16 acc[MT][NTL];
@@ -248,12 +299,13 @@ typedef void (*gemm_fn)(const GemmP);
 struct TileEntry {
   const char* name;
   int BM, BN, nthr, lds;
-  gemm_fn fn;
+  gemm_fn fn, conv_fn;
 };
 
 #define TILE_ENTRY(BM, BN, WM, WN)                                                   \
   { #BM "x" #BN "_w" #WM "x" #WN, BM, BN, TileCfg<BM, BN, WM, WN>::NTHR,            \
-    TileCfg<BM, BN, WM, WN>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN> }
+    TileCfg<BM, BN, WM, WN>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, false>, \
+    (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, true> }
 
 const TileEntry kTiles[] = {
     TILE_ENTRY(256, 192, 4, 2),  // 0: N % 192 == 0 shapes (d=1536): 8192x1536 -> exactly 256 tiles
@@ -264,7 +316,7 @@ const TileEntry kTiles[] = {
     TILE_ENTRY(128, 128, 2, 2),  // 5: small / ragged problems, 2 workgroups per CU
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
-bool g_attr_set[kNumTiles] = {};
+int g_attr_lds[kNumTiles][2] = {};
 
 int pick_tile(int M, int N) {
   // minimise (#rounds over 256 CUs) x (tile area incl. padding waste); prefer bigger tiles on ties.
@@ -285,6 +337,22 @@ int pick_tile(int M, int N) {
   return bi;
 }
 
+int launch(const GemmP& p, int ti, bool conv, void* stream) {
+  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N);
+  const TileEntry& e = kTiles[ti];
+  const gemm_fn fn = conv ? e.conv_fn : e.fn;
+  const int lds = e.lds + (conv ? p.K / 8 * 4 : 0);
+  if (lds > 160 * 1024) return V3A_ERR_SHAPE;
+  if (g_attr_lds[ti][conv] < lds) {
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return V3A_ERR_LAUNCH;
+    g_attr_lds[ti][conv] = lds;
+  }
+  const long tiles = (long)((p.M + e.BM - 1) / e.BM) * ((p.N + e.BN - 1) / e.BN);
+  hipLaunchKernelGGL(fn, dim3((unsigned)tiles), dim3(e.nthr), lds, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" int v3a_gemm_num_tiles(void) { return kNumTiles; }
@@ -297,22 +365,36 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   if (a->residual && (a->ldr % 8)) return V3A_ERR_SHAPE;
   if ((a->flags & V3A_GEMM_SCALE_PER_BATCH) && a->scale && a->rows_per_batch <= 0) return V3A_ERR_ARG;
   if (a->flags & V3A_GEMM_NO_ROUND_ACC) return V3A_ERR_ARG;  // not implemented: accumulators are parked as bf16
-  int ti = a->tile;
-  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(a->M, a->N);
-  const TileEntry& e = kTiles[ti];
-  GemmP p;
+  GemmP p = {};
   p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C;
   p.bias = a->bias; p.res = (const char*)a->residual; p.scale = a->scale;
   p.M = a->M; p.N = a->N; p.K = a->K;
   p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : 1; p.sstride = a->scale_stride;
   p.act = a->act; p.flags = a->flags;
-  if (!g_attr_set[ti]) {
-    if (hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, e.lds) != hipSuccess)
-      return V3A_ERR_LAUNCH;
-    g_attr_set[ti] = true;
-  }
-  const long tiles = (long)((a->M + e.BM - 1) / e.BM) * ((a->N + e.BN - 1) / e.BN);
-  hipLaunchKernelGGL(e.fn, dim3((unsigned)tiles), dim3(e.nthr), e.lds, (hipStream_t)stream, p);
-  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+  return launch(p, a->tile, false, stream);
+}
+
+extern "C" int v3a_conv_bf16(const v3a_conv_args* a, void* stream) {
+  if (!a || !a->x || !a->w || !a->y || !a->ktab) return V3A_ERR_ARG;
+  if (a->T <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->oT <= 0 || a->oH <= 0 || a->oW <= 0 || a->Cout <= 0)
+    return V3A_ERR_SHAPE;
+  if (a->Cin % 8 || a->Cout % 8 || a->Kpad % 64 || a->ldy % 8 || a->Kpad / 8 > 4096) return V3A_ERR_SHAPE;
+  if (a->residual && (a->ldr % 8)) return V3A_ERR_SHAPE;
+  if ((long)a->oT * a->oH * a->oW > 0x7fffffffL) return V3A_ERR_SHAPE;
+  if (a->flags & (V3A_GEMM_BIAS_ROW | V3A_GEMM_NO_ROUND_ACC)) return V3A_ERR_ARG;
+  GemmP p = {};
+  p.A = (const char*)a->x; p.B = (const char*)a->w; p.C = (char*)a->y;
+  p.bias = a->bias; p.res = (const char*)a->residual; p.scale = a->scale;
+  p.M = a->oT * a->oH * a->oW; p.N = a->Cout; p.K = a->Kpad;
+  p.lda = 0; p.ldb = a->Kpad; p.ldc = a->ldy; p.ldr = a->ldr;
+  p.rpb = 1; p.sstride = 0;
+  p.act = a->act; p.flags = a->flags & ~V3A_GEMM_SCALE_PER_BATCH;
+  p.ktab = a->ktab;
+  p.cT = a->T; p.cH = a->H; p.cW = a->W; p.cCin = a->Cin;
+  p.oH = a->oH; p.oW = a->oW;
+  p.sT = a->sT; p.sH = a->sH; p.sW = a->sW;
+  p.pT = a->pT; p.pH = a->pH; p.pW = a->pW;
+  p.ups = a->ups2 ? 1 : 0; p.replicate = a->replicate ? 1 : 0;
+  return launch(p, a->tile, true, stream);
 }

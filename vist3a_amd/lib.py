@@ -32,6 +32,20 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("ktab", C.c_void_p), ("y", C.c_void_p),
+        ("bias", C.c_void_p), ("residual", C.c_void_p), ("scale", C.c_void_p),
+        ("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int),
+        ("oT", C.c_int), ("oH", C.c_int), ("oW", C.c_int), ("Cout", C.c_int), ("Kpad", C.c_int),
+        ("sT", C.c_int), ("sH", C.c_int), ("sW", C.c_int),
+        ("pT", C.c_int), ("pH", C.c_int), ("pW", C.c_int),
+        ("ups2", C.c_int), ("replicate", C.c_int),
+        ("ldy", C.c_int), ("ldr", C.c_int),
+        ("act", C.c_int), ("flags", C.c_int), ("tile", C.c_int),
+    ]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p),
@@ -72,6 +86,7 @@ SYMBOLS = {
     "v3a_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "v3a_gemm_num_tiles": (C.c_int, []),
     "v3a_gemm_tile_name": (C.c_char_p, [C.c_int]),
+    "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "v3a_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "v3a_rmsnorm_rope": (C.c_int, [C.POINTER(RmsNormRopeArgs), C.c_void_p]),

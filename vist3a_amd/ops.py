@@ -95,6 +95,89 @@ def gemm(
     return out
 
 
+class ConvWeight:
+    """A convolution weight packed for v3a_conv_bf16: w[CoutPad][Kpad] bf16 (k = tap-major, channel-minor), the
+    K-chunk table, f32 bias.  Cin/Cout are padded to multiples of 8 with zeros (activations must carry CinPad)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device="cuda"):
+        w = weight.detach()
+        if w.dim() == 4:  # conv2d -> kT = 1
+            w = w[:, :, None]
+        if w.dim() == 3:  # conv1d
+            w = w[:, :, None, None]
+        Cout, Cin, kT, kH, kW = w.shape
+        self.Cout, self.Cin, self.k = Cout, Cin, (kT, kH, kW)
+        self.CinP, self.CoutP = (Cin + 7) // 8 * 8, (Cout + 7) // 8 * 8
+        K = kT * kH * kW * self.CinP
+        self.Kpad = (K + 63) // 64 * 64
+        wp = torch.zeros(self.CoutP, kT, kH, kW, self.CinP, dtype=f32)
+        wp[:Cout, :, :, :, :Cin] = w.float().permute(0, 2, 3, 4, 1).cpu()
+        full = torch.zeros(self.CoutP, self.Kpad, dtype=f32)
+        full[:, :K] = wp.reshape(self.CoutP, K)
+        self.w = full.to(device=device, dtype=bf16).contiguous()
+        tab = torch.zeros(self.Kpad // 8, dtype=torch.int64)
+        idx = torch.arange(K // 8)
+        tap, c8 = idx // (self.CinP // 8), idx % (self.CinP // 8)
+        dt, dh, dw = tap // (kH * kW), (tap // kW) % kH, tap % kW
+        tab[: K // 8] = (c8 * 8) | (dw << 16) | (dh << 20) | (dt << 24) | (1 << 31)
+        tab = torch.where(tab >= 2 ** 31, tab - 2 ** 32, tab)
+        self.ktab = tab.to(torch.int32).to(device).contiguous()
+        b = torch.zeros(self.CoutP, dtype=f32)
+        if bias is not None:
+            b[:Cout] = bias.detach().float().cpu()
+        self.bias = b.to(device)
+        self.has_bias = bias is not None
+
+
+def conv(
+    x: torch.Tensor, cw: ConvWeight, *, out: Optional[torch.Tensor] = None,
+    stride=(1, 1, 1), pad=(0, 0, 0), out_size=None, ups2: bool = False, replicate: bool = False,
+    act: int = L.ACT_NONE, residual: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+    out_f32: bool = False, tile: int = -1,
+) -> torch.Tensor:
+    """x: channels-last [T,H,W,CinP] bf16 contiguous -> out [oT,oH,oW,CoutP].  pad = LEADING pad per dim.  Spatial
+    dims follow PyTorch's symmetric-pad formula; the temporal dim is causal (all padding leading) when
+    pad_T == k_T - 1 and symmetric otherwise.  `out_size` overrides."""
+    if x.dim() != 4 or not x.is_contiguous() or x.dtype != bf16 or not x.is_cuda:
+        raise ValueError("x must be a contiguous device bf16 tensor [T,H,W,C]")
+    T, H, W, Cin = x.shape
+    if Cin != cw.CinP:
+        raise ValueError(f"x has {Cin} channels, packed weight expects {cw.CinP}")
+    kT, kH, kW = cw.k
+    eH, eW = (2 * H, 2 * W) if ups2 else (H, W)
+    if out_size is None:
+        if kT > 1 and pad[0] == kT - 1:
+            oT = (T + pad[0] - kT) // stride[0] + 1
+        else:
+            oT = (T + 2 * pad[0] - kT) // stride[0] + 1
+        oH = (eH + 2 * pad[1] - kH) // stride[1] + 1
+        oW = (eW + 2 * pad[2] - kW) // stride[2] + 1
+    else:
+        oT, oH, oW = out_size
+    M = oT * oH * oW
+    if out is None:
+        out = torch.empty((oT, oH, oW, cw.CoutP), device=x.device, dtype=f32 if out_f32 else bf16)
+    o2 = out.view(M, out.shape[-1])
+    flags = 0
+    ldr = 0
+    r2 = None
+    if residual is not None:
+        r2 = residual.view(M, residual.shape[-1])
+        if r2.dtype == f32:
+            flags |= L.GEMM_RES_F32
+        ldr = r2.stride(0)
+    if out_f32:
+        flags |= L.GEMM_OUT_F32
+    args = L.ConvArgs(
+        _ptr(x), _ptr(cw.w), _ptr(cw.ktab), _ptr(o2), _ptr(cw.bias if cw.has_bias else None), _ptr(r2), _ptr(scale),
+        T, H, W, Cin, oT, oH, oW, cw.CoutP, cw.Kpad,
+        stride[0], stride[1], stride[2], pad[0], pad[1], pad[2],
+        int(ups2), int(replicate), o2.stride(0), ldr, act, flags, tile,
+    )
+    L.check(L.load().v3a_conv_bf16(C.byref(args), _stream()), "v3a_conv_bf16")
+    return out
+
+
 def attention(
     q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *,
     B: int, H: int, Nq: int, Nk: int, D: int,
