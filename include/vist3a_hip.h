@@ -140,6 +140,21 @@ typedef struct {
 } v3a_rmsnorm_rope_args;
 int v3a_rmsnorm_rope(const v3a_rmsnorm_rope_args* args, void* stream);
 
+/* Channel norm over channels-last pixels (+ optional SiLU): mode 0 RMSNorm(eps); mode 1 = F.normalize(x,dim=C)
+ * * sqrt(C) * gamma (+ bias), i.e. WanRMS_norm (/root/reference/utils/wan_utils.py:150-184) fused with the SiLU that
+ * follows it in WanResidualBlock (:370-372,:399-400) and WanDecoder3d (:873-874). bf16 in / bf16 out. */
+typedef struct {
+  const void* x; void* y;
+  const float* weight; const float* bias;   /* [d]; bias may be NULL */
+  long M; int d, ldx, ldy;
+  float eps; int mode; int act;             /* act: V3A_ACT_NONE or V3A_ACT_SILU */
+} v3a_rownorm_args;
+int v3a_rownorm_act(const v3a_rownorm_args* args, void* stream);
+
+/* P[M,N] (bf16) = softmax(scale * S[M,N]) (f32), row-wise.  The VAE mid-block's single 384-wide head
+ * (/root/reference/utils/wan_utils.py:428-475) runs as GEMM -> this -> GEMM. */
+int v3a_softmax_rows(const float* s, void* p, int M, int N, int lds, int ldp, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

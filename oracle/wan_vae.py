@@ -1,0 +1,161 @@
+"""ORACLE (test infrastructure).  CPU fp32 restatement of the Wan-2.1 VAE *decoder* (SURVEY.md §8a rows V1-V7).
+
+Follows /root/reference/utils/wan_utils.py (the vendored twin of diffusers' AutoencoderKLWan that
+`pipe.vae.decode` runs at /root/reference/inference_t23d.py:114):
+    WanCausalConv3d :96-147   WanRMS_norm :150-184   WanResample :202-330   WanResidualBlock :333-425
+    WanAttentionBlock :428-475   WanMidBlock :478-531   WanUpBlock :667-749   WanDecoder3d :752-901
+    AutoencoderKLWan._decode :1078-1117
+PARITY PINNED: tests/golden/vae_decode_tiny.safetensors is produced by running the reference module itself
+(tests/golden/make_golden.py, stub-imported in the build container) on weights from `make_weights` below.
+
+The reference decodes one latent frame per call and threads a cache of the last two input frames through every
+causal conv.  That is arithmetically a causal convolution over the whole frame sequence (two zero frames in
+front), with ONE quirk that this restatement keeps: in `upsample3d` the first latent frame skips `time_conv`
+("Rep" sentinel, :256-267) and the time_conv of the remaining frames never sees it (zero context instead, :283-297).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class WanVAEConfig:
+    base_dim: int = 96
+    z_dim: int = 16
+    dim_mult: List[int] = field(default_factory=lambda: [1, 2, 4, 4])
+    num_res_blocks: int = 2
+    temperal_downsample: List[bool] = field(default_factory=lambda: [False, True, True])
+
+    def decoder_plan(self):
+        """[(in_dim, out_dim, upsample_mode)] per up block, as WanDecoder3d.__init__ (:783-812)."""
+        dims = [self.base_dim * u for u in [self.dim_mult[-1]] + self.dim_mult[::-1]]
+        tu = self.temperal_downsample[::-1]
+        plan = []
+        for i, (i_d, o_d) in enumerate(zip(dims[:-1], dims[1:])):
+            if i > 0:
+                i_d = i_d // 2
+            mode = None
+            if i != len(self.dim_mult) - 1:
+                mode = "upsample3d" if tu[i] else "upsample2d"
+            plan.append((i_d, o_d, mode))
+        return dims[0], plan
+
+
+def causal_conv3d(x, w, b, pad):
+    """x [B,C,T,H,W]; zero pad (W,W,H,H,2*pT,0) then valid conv (WanCausalConv3d.forward without cache)."""
+    pt, ph, pw = pad
+    return F.conv3d(F.pad(x, (pw, pw, ph, ph, 2 * pt, 0)), w, b)
+
+
+def rms_norm(x, gamma, dim=1):
+    return F.normalize(x, dim=dim) * (x.shape[dim] ** 0.5) * gamma
+
+
+def res_block(sd, p, x):
+    h = x
+    if p + "conv_shortcut.weight" in sd:
+        h = causal_conv3d(x, sd[p + "conv_shortcut.weight"], sd[p + "conv_shortcut.bias"], (0, 0, 0))
+    x = F.silu(rms_norm(x, sd[p + "norm1.gamma"]))
+    x = causal_conv3d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], (1, 1, 1))
+    x = F.silu(rms_norm(x, sd[p + "norm2.gamma"]))
+    x = causal_conv3d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"], (1, 1, 1))
+    return x + h
+
+
+def attn_block(sd, p, x):
+    B, C, T, H, W = x.shape
+    idn = x
+    y = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    y = rms_norm(y, sd[p + "norm.gamma"])
+    qkv = F.conv2d(y, sd[p + "to_qkv.weight"], sd[p + "to_qkv.bias"])
+    qkv = qkv.reshape(B * T, 1, C * 3, -1).permute(0, 1, 3, 2).contiguous()
+    q, k, v = qkv.chunk(3, dim=-1)
+    y = F.scaled_dot_product_attention(q, k, v)
+    y = y.squeeze(1).permute(0, 2, 1).reshape(B * T, C, H, W)
+    y = F.conv2d(y, sd[p + "proj.weight"], sd[p + "proj.bias"])
+    return y.view(B, T, C, H, W).permute(0, 2, 1, 3, 4) + idn
+
+
+def resample(sd, p, x, mode):
+    B, C, T, H, W = x.shape
+    if mode == "upsample3d" and T > 1:
+        rest = causal_conv3d(x[:, :, 1:], sd[p + "time_conv.weight"], sd[p + "time_conv.bias"], (1, 0, 0))  # [B,2C,T-1,H,W]
+        rest = rest.reshape(B, 2, C, T - 1, H, W)
+        rest = torch.stack((rest[:, 0], rest[:, 1]), 3).reshape(B, C, 2 * (T - 1), H, W)
+        x = torch.cat([x[:, :, :1], rest], 2)
+        T = x.shape[2]
+    y = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    y = F.interpolate(y.float(), scale_factor=(2.0, 2.0), mode="nearest-exact")
+    y = F.conv2d(y, sd[p + "resample.1.weight"], sd[p + "resample.1.bias"], padding=1)
+    return y.view(B, T, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
+
+
+def decode(sd: Dict[str, torch.Tensor], cfg: WanVAEConfig, z: torch.Tensor) -> torch.Tensor:
+    """AutoencoderKLWan._decode: z [B,16,T_lat,h,w] (de-normalised latents) -> video [B,3,1+4(T_lat-1),8h,8w] in [-1,1]."""
+    sd = {k: v.float() for k, v in sd.items()}
+    x = causal_conv3d(z.float(), sd["post_quant_conv.weight"], sd["post_quant_conv.bias"], (0, 0, 0))
+    d = "decoder."
+    x = causal_conv3d(x, sd[d + "conv_in.weight"], sd[d + "conv_in.bias"], (1, 1, 1))
+    x = res_block(sd, d + "mid_block.resnets.0.", x)
+    x = attn_block(sd, d + "mid_block.attentions.0.", x)
+    x = res_block(sd, d + "mid_block.resnets.1.", x)
+    _, plan = cfg.decoder_plan()
+    for i, (_, _, mode) in enumerate(plan):
+        for j in range(cfg.num_res_blocks + 1):
+            x = res_block(sd, d + f"up_blocks.{i}.resnets.{j}.", x)
+        if mode is not None:
+            x = resample(sd, d + f"up_blocks.{i}.upsamplers.0.", x, mode)
+    x = F.silu(rms_norm(x, sd[d + "norm_out.gamma"]))
+    x = causal_conv3d(x, sd[d + "conv_out.weight"], sd[d + "conv_out.bias"], (1, 1, 1))
+    return torch.clamp(x, -1.0, 1.0)
+
+
+def make_weights(cfg: WanVAEConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded decoder(+post_quant_conv) weights under the reference's state-dict names."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, o, i, k):
+        fan = i * math.prod(k)
+        sd[name + ".weight"] = torch.randn(o, i, *k, generator=g) / math.sqrt(fan)
+        sd[name + ".bias"] = torch.randn(o, generator=g) * 0.05
+
+    def gamma(name, c, nd):
+        sd[name + ".gamma"] = 1 + 0.1 * torch.randn(c, *([1] * nd), generator=g)
+
+    def res(p, i, o):
+        gamma(p + "norm1", i, 3)
+        conv(p + "conv1", o, i, (3, 3, 3))
+        gamma(p + "norm2", o, 3)
+        conv(p + "conv2", o, o, (3, 3, 3))
+        if i != o:
+            conv(p + "conv_shortcut", o, i, (1, 1, 1))
+
+    conv("post_quant_conv", cfg.z_dim, cfg.z_dim, (1, 1, 1))
+    d0, plan = cfg.decoder_plan()
+    d = "decoder."
+    conv(d + "conv_in", d0, cfg.z_dim, (3, 3, 3))
+    res(d + "mid_block.resnets.0.", d0, d0)
+    gamma(d + "mid_block.attentions.0.norm", d0, 2)
+    conv(d + "mid_block.attentions.0.to_qkv", 3 * d0, d0, (1, 1))
+    conv(d + "mid_block.attentions.0.proj", d0, d0, (1, 1))
+    res(d + "mid_block.resnets.1.", d0, d0)
+    for i, (i_d, o_d, mode) in enumerate(plan):
+        cur = i_d
+        for j in range(cfg.num_res_blocks + 1):
+            res(d + f"up_blocks.{i}.resnets.{j}.", cur, o_d)
+            cur = o_d
+        if mode is not None:
+            conv(d + f"up_blocks.{i}.upsamplers.0.resample.1", o_d // 2, o_d, (3, 3))
+            if mode == "upsample3d":
+                conv(d + f"up_blocks.{i}.upsamplers.0.time_conv", 2 * o_d, o_d, (3, 1, 1))
+    gamma(d + "norm_out", plan[-1][1], 3)
+    conv(d + "conv_out", 3, plan[-1][1], (3, 3, 3))
+    sd[d + "conv_out.weight"] *= 0.25  # keep most of the output inside the final clamp(-1, 1)
+    sd[d + "conv_out.bias"] *= 0.25
+    return sd

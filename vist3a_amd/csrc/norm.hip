@@ -139,6 +139,97 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const RmsP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Channel norm over short rows (channels-last pixels): LPR lanes (power of two) share one row, CPL
+// 16-byte chunks each; 64/LPR rows per wave.  mode 0: RMSNorm  x*rsqrt(mean(x^2)+eps)*w
+//                                             mode 1: F.normalize semantics  x/max(||x||,1e-12)*sqrt(d)*w (+b)
+// optional SiLU.  WanRMS_norm + nonlinearity: /root/reference/utils/wan_utils.py:150-184, :370-372.
+struct RowNormP {
+  const char* x; char* y;
+  const float* w; const float* b;
+  long M;
+  int d, ldx, ldy, lpr, mode, act;
+  float eps;
+};
+
+template <int CPL>
+__global__ __launch_bounds__(256) void rownorm_kernel(const RowNormP p) {
+  const int lane = threadIdx.x & 63;
+  const int lpr = p.lpr, rpw = 64 / lpr;
+  const int j = lane & (lpr - 1), r = lane / lpr;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + r;
+  const int nch = p.d >> 3;
+  const bool live = row < p.M;
+  float v[CPL][8];
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = j + i * lpr;
+    if (live && c < nch) {
+      const u32x4 raw = *(const u32x4*)(p.x + ((size_t)row * p.ldx + c * 8) * 2);
+      unpack_bf16x8(raw, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sq += v[i][e] * v[i][e];
+    }
+  }
+  for (int o = lpr >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  float rs;
+  if (p.mode == 0) rs = rsqrtf(sq / (float)p.d + p.eps);
+  else rs = sqrtf((float)p.d) / fmaxf(sqrtf(sq), 1e-12f);
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = j + i * lpr;
+    if (c >= nch) continue;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = v[i][e] * rs * p.w[c * 8 + e];
+      if (p.b) t += p.b[c * 8 + e];
+      if (p.act == V3A_ACT_SILU) t = silu(t);
+      o[e] = t;
+    }
+    *(u32x4*)(p.y + ((size_t)row * p.ldy + c * 8) * 2) = pack_bf16x8(o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax  P = softmax(scale * S), S f32 [M][N] -> P bf16 [M][N]; one wave per row, online
+// max/sum pass then a normalise pass (second read is L2 resident).  Used by the single-head
+// C=384 VAE mid-block attention (/root/reference/utils/wan_utils.py:428-475) whose head width
+// exceeds the flash kernel's register budget.
+struct SoftmaxP { const float* s; char* p; int M, N, lds, ldp; float scale_log2e; };
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const SoftmaxP p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const float* sr = p.s + (size_t)row * p.lds;
+  const int nv = p.N >> 2;
+  float m = -1e30f, l = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    const f32x4 x = *(const f32x4*)(sr + i * 4);
+    const float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])) * p.scale_log2e;
+    const float mn = fmaxf(m, mx);
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc += __builtin_amdgcn_exp2f(x[e] * p.scale_log2e - mn);
+    l = l * __builtin_amdgcn_exp2f(m - mn) + acc;
+    m = mn;
+  }
+  const float mw = wave_max(m);
+  l = wave_sum(l * __builtin_amdgcn_exp2f(m - mw));
+  const float inv = 1.f / l;
+  char* pr = p.p + (size_t)row * p.ldp * 2;
+  for (int i = lane; i < nv; i += 64) {
+    const f32x4 x = *(const f32x4*)(sr + i * 4);
+    u32x2 o;
+    o[0] = pack_bf16x2(__builtin_amdgcn_exp2f(x[0] * p.scale_log2e - mw) * inv, __builtin_amdgcn_exp2f(x[1] * p.scale_log2e - mw) * inv);
+    o[1] = pack_bf16x2(__builtin_amdgcn_exp2f(x[2] * p.scale_log2e - mw) * inv, __builtin_amdgcn_exp2f(x[3] * p.scale_log2e - mw) * inv);
+    *(u32x2*)(pr + i * 8) = o;
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_CPL(KERNEL, P, d, grid, stream)                                             \
@@ -179,5 +270,44 @@ extern "C" int v3a_rmsnorm_rope(const v3a_rmsnorm_rope_args* a, void* stream) {
   p.eps = a->eps;
   const dim3 grid((a->M + 3) / 4);
   DISPATCH_CPL(rmsnorm_rope_kernel, p, a->d, grid, stream);
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}
+
+extern "C" int v3a_rownorm_act(const v3a_rownorm_args* a, void* stream) {
+  if (!a || !a->x || !a->y || !a->weight) return V3A_ERR_ARG;
+  if (a->M <= 0 || a->d <= 0 || a->d % 8 || a->ldx % 8 || a->ldy % 8) return V3A_ERR_SHAPE;
+  const int nch = a->d / 8;
+  // choose chunks-per-lane / lanes-per-row (power of two) with the least idle lanes
+  int best_cpl = 0, best_lpr = 0, best_waste = 1 << 30;
+  for (int cpl = 1; cpl <= 4; ++cpl) {
+    int need = (nch + cpl - 1) / cpl, lpr = 1;
+    while (lpr < need) lpr <<= 1;
+    if (lpr > 64) continue;
+    const int waste = lpr * cpl - nch;
+    if (waste < best_waste) { best_waste = waste; best_cpl = cpl; best_lpr = lpr; }
+  }
+  if (!best_cpl) return V3A_ERR_SHAPE;
+  RowNormP p;
+  p.x = (const char*)a->x; p.y = (char*)a->y; p.w = a->weight; p.b = a->bias;
+  p.M = a->M; p.d = a->d; p.ldx = a->ldx; p.ldy = a->ldy; p.lpr = best_lpr; p.mode = a->mode; p.act = a->act;
+  p.eps = a->eps;
+  const long rpb = 4L * (64 / best_lpr);
+  const dim3 grid((unsigned)((a->M + rpb - 1) / rpb));
+  switch (best_cpl) {
+    case 1: hipLaunchKernelGGL(rownorm_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    case 2: hipLaunchKernelGGL(rownorm_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    case 3: hipLaunchKernelGGL(rownorm_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL(rownorm_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p); break;
+  }
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}
+
+extern "C" int v3a_softmax_rows(const float* s, void* p, int M, int N, int lds, int ldp, float scale, void* stream) {
+  if (!s || !p) return V3A_ERR_ARG;
+  if (M <= 0 || N <= 0 || N % 4 || lds % 4 || ldp % 4) return V3A_ERR_SHAPE;
+  SoftmaxP sp;
+  sp.s = s; sp.p = (char*)p; sp.M = M; sp.N = N; sp.lds = lds; sp.ldp = ldp;
+  sp.scale_log2e = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, sp);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }

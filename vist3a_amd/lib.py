@@ -79,6 +79,14 @@ class RmsNormRopeArgs(C.Structure):
     ]
 
 
+class RowNormArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("weight", C.c_void_p), ("bias", C.c_void_p),
+        ("M", C.c_long), ("d", C.c_int), ("ldx", C.c_int), ("ldy", C.c_int),
+        ("eps", C.c_float), ("mode", C.c_int), ("act", C.c_int),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/vist3a_hip.h declares must be listed here
 SYMBOLS = {
     "v3a_abi_version": (C.c_int, []),
@@ -90,6 +98,8 @@ SYMBOLS = {
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "v3a_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "v3a_rmsnorm_rope": (C.c_int, [C.POINTER(RmsNormRopeArgs), C.c_void_p]),
+    "v3a_rownorm_act": (C.c_int, [C.POINTER(RowNormArgs), C.c_void_p]),
+    "v3a_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
 }
 
 _lib = None

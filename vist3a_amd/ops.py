@@ -246,3 +246,30 @@ def rmsnorm_rope(
     )
     L.check(L.load().v3a_rmsnorm_rope(C.byref(args), _stream()), "v3a_rmsnorm_rope")
     return out
+
+
+def rownorm_act(x: torch.Tensor, weight: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, mode: int = 1, act: int = L.ACT_NONE, eps: float = 1e-6) -> torch.Tensor:
+    """Channel norm (+SiLU) over the last dim of a channels-last bf16 tensor (any leading dims, contiguous)."""
+    if x.dtype != bf16 or not x.is_cuda or not x.is_contiguous():
+        raise ValueError("x must be contiguous device bf16")
+    d = x.shape[-1]
+    M = x.numel() // d
+    if out is None:
+        out = torch.empty_like(x)
+    if weight.dtype != f32 or weight.numel() != d or not weight.is_contiguous():
+        raise ValueError("weight must be contiguous f32 [d]")
+    args = L.RowNormArgs(_ptr(x), _ptr(out), _ptr(weight), _ptr(bias), M, d, d, d, eps, mode, act)
+    L.check(L.load().v3a_rownorm_act(C.byref(args), _stream()), "v3a_rownorm_act")
+    return out
+
+
+def softmax_rows(s: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk2d(s, "s", (f32,))
+    M, N = s.shape
+    if out is None:
+        out = torch.empty((M, N), device=s.device, dtype=bf16)
+    _chk2d(out, "out", (bf16,))
+    L.check(L.load().v3a_softmax_rows(_ptr(s), _ptr(out), M, N, s.stride(0), out.stride(0), float(scale), _stream()),
+            "v3a_softmax_rows")
+    return out

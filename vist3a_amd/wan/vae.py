@@ -1,0 +1,150 @@
+"""Wan-2.1 VAE decoder on MI355X — the `pipe.vae.decode(latents, return_dict=False)[0]`
+call of /root/reference/inference_t23d.py:114 (architecture: /root/reference/utils/wan_utils.py:752-901, 1078-1117).
+
+MI355X-first restructuring (identical arithmetic, different schedule):
+  * the reference decodes ONE latent frame per call and threads a two-frame cache through ~33 causal convs; here the
+    whole clip is decoded in one pass — every WanCausalConv3d becomes one implicit-GEMM launch over all frames with
+    causal (leading) zero padding, so the GEMM M dimension is T·H·W instead of H·W;
+  * activations are channels-last bf16 [T,H,W,C]: the conv K dimension (taps x Cin) is contiguous per pixel and is
+    gathered straight into LDS by the kernel's DMA — no im2col buffer, no NCHW<->NHWC traffic between layers;
+  * RMS-norm + SiLU is one read-once/write-once kernel; nearest-exact 2x upsampling is folded into the following
+    conv's gather (the 4x larger tensor is never written); residual adds ride in conv epilogues;
+  * the "Rep" quirk of upsample3d is kept: the first frame bypasses time_conv and is invisible to it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+import torch
+
+from .. import lib as L
+from .. import ops
+
+bf16, f32 = torch.bfloat16, torch.float32
+
+
+@dataclass
+class WanVAEConfig:
+    base_dim: int = 96
+    z_dim: int = 16
+    dim_mult: List[int] = field(default_factory=lambda: [1, 2, 4, 4])
+    num_res_blocks: int = 2
+    temperal_downsample: List[bool] = field(default_factory=lambda: [False, True, True])
+
+    def decoder_plan(self):
+        dims = [self.base_dim * u for u in [self.dim_mult[-1]] + self.dim_mult[::-1]]
+        tu = self.temperal_downsample[::-1]
+        plan = []
+        for i, (i_d, o_d) in enumerate(zip(dims[:-1], dims[1:])):
+            if i > 0:
+                i_d = i_d // 2
+            mode = None
+            if i != len(self.dim_mult) - 1:
+                mode = "upsample3d" if tu[i] else "upsample2d"
+            plan.append((i_d, o_d, mode))
+        return dims[0], plan
+
+
+class _Res:
+    def __init__(self, sd, p, dev):
+        g = lambda k: sd[k].reshape(-1).to(device=dev, dtype=f32).contiguous()
+        cw = lambda n: ops.ConvWeight(sd[p + n + ".weight"], sd[p + n + ".bias"], device=dev)
+        self.g1, self.g2 = g(p + "norm1.gamma"), g(p + "norm2.gamma")
+        self.c1, self.c2 = cw("conv1"), cw("conv2")
+        self.sc = cw("conv_shortcut") if p + "conv_shortcut.weight" in sd else None
+
+    def __call__(self, x):
+        h = x if self.sc is None else ops.conv(x, self.sc)
+        n = ops.rownorm_act(x, self.g1, mode=1, act=L.ACT_SILU)
+        y = ops.conv(n, self.c1, pad=(2, 1, 1))
+        n = ops.rownorm_act(y, self.g2, mode=1, act=L.ACT_SILU)
+        return ops.conv(n, self.c2, pad=(2, 1, 1), residual=h)
+
+
+class WanVAEDecoder:
+    """decode(z) with the AutoencoderKLWan.decode signature subset the reference uses."""
+
+    def __init__(self, cfg: WanVAEConfig, state_dict: Dict[str, torch.Tensor], device="cuda"):
+        L.load()
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), bf16
+        sd, dev = state_dict, self.device
+        cw = lambda n: ops.ConvWeight(sd[n + ".weight"], sd[n + ".bias"], device=dev)
+        g = lambda k: sd[k].reshape(-1).to(device=dev, dtype=f32).contiguous()
+        d = "decoder."
+        self.pq = cw("post_quant_conv")
+        self.conv_in = cw(d + "conv_in")
+        self.mid0 = _Res(sd, d + "mid_block.resnets.0.", dev)
+        self.mid1 = _Res(sd, d + "mid_block.resnets.1.", dev)
+        a = d + "mid_block.attentions.0."
+        C = sd[a + "proj.weight"].shape[0]
+        self.attn_C = C
+        self.attn_g = g(a + "norm.gamma")
+        wqkv = sd[a + "to_qkv.weight"].reshape(3 * C, C)
+        bqkv = sd[a + "to_qkv.bias"]
+        self.wqk = wqkv[: 2 * C].to(device=dev, dtype=bf16).contiguous()
+        self.bqk = bqkv[: 2 * C].to(device=dev, dtype=f32).contiguous()
+        self.wv = wqkv[2 * C:].to(device=dev, dtype=bf16).contiguous()
+        self.bv = bqkv[2 * C:].to(device=dev, dtype=f32).contiguous()
+        self.wproj = sd[a + "proj.weight"].reshape(C, C).to(device=dev, dtype=bf16).contiguous()
+        self.bproj = sd[a + "proj.bias"].to(device=dev, dtype=f32).contiguous()
+        _, plan = cfg.decoder_plan()
+        self.ups = []
+        for i, (_, o_d, mode) in enumerate(plan):
+            res = [_Res(sd, d + f"up_blocks.{i}.resnets.{j}.", dev) for j in range(cfg.num_res_blocks + 1)]
+            rs = tc = None
+            if mode is not None:
+                rs = cw(d + f"up_blocks.{i}.upsamplers.0.resample.1")
+                if mode == "upsample3d":
+                    tc = cw(d + f"up_blocks.{i}.upsamplers.0.time_conv")
+            self.ups.append((res, mode, rs, tc, o_d))
+        self.g_out = g(d + "norm_out.gamma")
+        self.conv_out = cw(d + "conv_out")
+
+    def _attn(self, x):
+        T, H, W, C = x.shape
+        HW = H * W
+        x2 = x.view(T * HW, C)
+        n = ops.rownorm_act(x, self.attn_g, mode=1).view(T * HW, C)
+        qk = ops.gemm(n, self.wqk, self.bqk)
+        o = torch.empty(T * HW, C, device=x.device, dtype=bf16)
+        s = torch.empty(HW, HW, device=x.device, dtype=f32)
+        pm = torch.empty(HW, HW, device=x.device, dtype=bf16)
+        vt = torch.empty(C, HW, device=x.device, dtype=bf16)
+        for t in range(T):  # one 384-wide head per frame: QK^T GEMM -> row softmax -> PV GEMM
+            sl = slice(t * HW, (t + 1) * HW)
+            ops.gemm(self.wv, n[sl], self.bv, out=vt, bias_row=True)
+            ops.gemm(qk[sl, :C], qk[sl, C:], out=s, out_f32=True)
+            ops.softmax_rows(s, C ** -0.5, out=pm)
+            ops.gemm(pm, vt, out=o[sl])
+        y = ops.gemm(o, self.wproj, self.bproj, residual=x2)
+        return y.view(T, H, W, C)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = False):
+        if z.dim() != 5 or z.shape[0] != 1:
+            raise ValueError("expected z [1, z_dim, T, h, w]")
+        x = z[0].permute(1, 2, 3, 0).to(device=self.device, dtype=bf16).contiguous()  # [T,h,w,16]
+        x = ops.conv(x, self.pq)
+        x = ops.conv(x, self.conv_in, pad=(2, 1, 1))
+        x = self.mid0(x)
+        x = self._attn(x)
+        x = self.mid1(x)
+        for res, mode, rs, tc, C in self.ups:
+            for r in res:
+                x = r(x)
+            if mode is None:
+                continue
+            T = x.shape[0]
+            if mode == "upsample3d" and T > 1:
+                rest = ops.conv(x[1:].contiguous(), tc, pad=(2, 0, 0))  # [T-1,H,W,2C]
+                y = torch.empty((1 + 2 * (T - 1), *x.shape[1:]), device=x.device, dtype=bf16)
+                y[0] = x[0]
+                y[1::2] = rest[..., :C]
+                y[2::2] = rest[..., C:]
+                x = y
+            x = ops.conv(x, rs, pad=(0, 1, 1), ups2=True)
+        n = ops.rownorm_act(x, self.g_out, mode=1, act=L.ACT_SILU)
+        y = ops.conv(n, self.conv_out, pad=(2, 1, 1))  # [T,H,W,8] (3 real channels)
+        video = y[..., :3].permute(3, 0, 1, 2).unsqueeze(0).clamp(-1.0, 1.0).contiguous()
+        return video if return_dict else (video,)
