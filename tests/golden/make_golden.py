@@ -51,7 +51,157 @@ def vae_decode_tiny():
     _save("vae_decode_tiny", {"z": z, "out": ref})
 
 
-GENERATORS = {f.__name__: f for f in [vae_decode_tiny]}
+def stitch_tiny():
+    """stitched_model.py:92-107 trilinear T-upsample + stitching_layer_builder.py ConvSpec.build (replicate pad)."""
+    from models.stitching_layer_builder import parse_conv_spec
+    from oracle import recon as R
+    spec = parse_conv_spec("conv3d_k5x3x3_o64_s1x2x2_p2x1x1")
+    layer = spec.build(in_channels=16)
+    g = torch.Generator().manual_seed(31)
+    with torch.no_grad():
+        layer.weight.copy_(torch.randn(layer.weight.shape, generator=g) / 27.0)
+        layer.bias.copy_(torch.randn(layer.bias.shape, generator=g) * 0.1)
+    lat = torch.randn(1, 16, 3, 8, 8, generator=g)
+    T = lat.shape[2]
+    with torch.no_grad():
+        up = torch.nn.functional.interpolate(lat, size=[(T - 1) * 4 + 1, 8, 8], mode="trilinear", align_corners=True)
+        ref = layer(up)
+        mine = R.stitch_conv(R.upsample_T(lat), layer.weight, layer.bias, (1, 2, 2), (2, 1, 1))
+    err = (ref - mine).abs().max().item()
+    print(f"stitch_tiny: oracle vs reference {err:.2e}; out {tuple(ref.shape)}")
+    assert err < 1e-5 and layer.padding_mode == "replicate"
+    _save("stitch_tiny", {"latent": lat, "weight": layer.weight.detach(), "bias": layer.bias.detach(), "out": ref})
+
+
+def _bare(cls):
+    import torch.nn as nn
+    o = cls.__new__(cls)
+    nn.Module.__init__(o)
+    return o
+
+
+RECON_TINY = dict(C=64, heads=1, n_dino=22, depth=24, cam_heads=2, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+
+
+def build_reference_stitched(cfg, sd):
+    """Assemble the reference's AnySplatStitched object at reduced width WITHOUT its checkpoint-downloading
+    constructors (from_pretrained), from the reference's own sub-module classes, and load `sd` into it."""
+    import types as _t
+    from functools import partial
+
+    import torch.nn as nn
+    from models.anysplat_stitched import AnySplatStitched
+    from third_party_model.anysplat.src.model.encoder.anysplat import EncoderAnySplat
+    from third_party_model.anysplat.src.model.encoder.common.gaussian_adapter import GaussianAdapterCfg, UnifiedGaussianAdapter
+    from third_party_model.anysplat.src.model.encoder.heads.vggt_dpt_gs_head import VGGT_DPT_GS_Head
+    from third_party_model.anysplat.src.model.encoder.vggt.heads.camera_head import CameraHead
+    from third_party_model.anysplat.src.model.encoder.vggt.heads.dpt_head import DPTHead
+    from third_party_model.anysplat.src.model.encoder.vggt.layers.attention import MemEffAttention
+    from third_party_model.anysplat.src.model.encoder.vggt.layers.block import Block
+    from third_party_model.anysplat.src.model.encoder.vggt.layers.vision_transformer import DinoVisionTransformer
+    from third_party_model.anysplat.src.model.encoder.vggt.models.aggregator import Aggregator
+
+    C = cfg.C
+    agg = Aggregator(img_size=518, patch_size=14, embed_dim=C, depth=cfg.depth, num_heads=cfg.heads, patch_embed="conv")
+    agg.use_checkpoint = False
+    dino = DinoVisionTransformer(img_size=518, patch_size=14, embed_dim=C, depth=cfg.n_dino, num_heads=cfg.heads, mlp_ratio=4,
+                                 block_fn=partial(Block, attn_class=MemEffAttention), num_register_tokens=4,
+                                 interpolate_antialias=True, interpolate_offset=0.0, block_chunks=0, init_values=1.0)
+    del dino.patch_embed  # what convert_model_to_stitched_model does (blocks already at the post-deletion count)
+    agg.patch_embed = dino
+    enc = _bare(EncoderAnySplat)
+    enc.aggregator = agg
+    enc.camera_head = CameraHead(dim_in=2 * C, trunk_depth=cfg.cam_trunk, num_heads=cfg.cam_heads)
+    for blk in enc.camera_head.trunk:
+        pass
+    enc.depth_head = DPTHead(dim_in=2 * C, output_dim=2, activation="exp", conf_activation="expp1", features=cfg.features,
+                             out_channels=list(cfg.oc))
+    enc.gaussian_adapter = UnifiedGaussianAdapter(GaussianAdapterCfg(gaussian_scale_min=0.5, gaussian_scale_max=15.0, sh_degree=cfg.sh_degree))
+    enc.raw_gs_dim = 1 + enc.gaussian_adapter.d_in
+    enc.gaussian_param_head = VGGT_DPT_GS_Head(dim_in=2 * C, patch_size=(14, 14), output_dim=enc.raw_gs_dim + 1, activation="norm_exp",
+                                               conf_activation="expp1", features=256, out_channels=list(cfg.oc))
+    enc.voxel_size = cfg.voxel_size
+    enc.cfg = _t.SimpleNamespace(pred_head_type="depth", render_conf=False, voxelize=cfg.voxelize, opacity_conf=False, conf_threshold=0.1,
+                                 opacity_mapping=_t.SimpleNamespace(initial=0.0, final=0.0, warm_up=1))
+    model = _bare(AnySplatStitched)
+    model.encoder = enc
+    model.grad_checkpointing = False
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys[:5]
+    miss = [k for k in res.missing_keys if "mask_token" not in k and "patch_embed.patch_embed" not in k]
+    assert not miss, miss[:8]
+    return model.eval()
+
+
+def recon_tiny():
+    """The reference's AnySplatStitched.forward at reduced width (C=64) but full depth (22 DINO + 24x2 aggregator blocks),
+    2 views @28x28, voxelisation active.  Pins the whole R3-R17 restatement end to end."""
+    from oracle import recon as R
+    cfg = R.ReconCfg(**RECON_TINY)
+    sd = R.make_recon_weights(cfg, seed=41)
+    model = build_reference_stitched(cfg, sd)
+    g = torch.Generator().manual_seed(42)
+    S, H, W = 2, 28, 28
+    lat = torch.randn(1, cfg.C, S, H // 14, W // 14, generator=g)
+    img = torch.rand(1, 3, S, H, W, generator=g) * 2 - 1
+    import contextlib, io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        ref = model(lat, img, False)
+        mine = R.recon_forward(sd, cfg, lat, img)
+    gs = ref.gaussians
+
+    def chk(name, a, b, tol=2e-4):
+        e = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-9)
+        print(f"  {name:22s} rel-max err {e:.2e}  shape {tuple(b.shape)}")
+        assert e < tol, name
+
+    print("recon_tiny: oracle vs reference")
+    chk("pose_enc", mine["pred_pose_enc_list"][-1], ref.pred_pose_enc_list[-1])
+    chk("depth", mine["depth"], ref.depth_dict["depth"])
+    chk("means", mine["gaussians"]["means"], gs.means)
+    chk("scales", mine["gaussians"]["scales"], gs.scales)
+    chk("rotations", mine["gaussians"]["rotations"], gs.rotations)
+    chk("harmonics", mine["gaussians"]["harmonics"], gs.harmonics)
+    chk("opacities", mine["gaussians"]["opacities"], gs.opacities)
+    chk("covariances", mine["gaussians"]["covariances"], gs.covariances, 2e-3)
+    chk("c2w", mine["pred_context_pose"]["extrinsic"], ref.pred_context_pose["extrinsic"])
+    chk("intrinsic", mine["pred_context_pose"]["intrinsic"], ref.pred_context_pose["intrinsic"])
+    U = gs.means.shape[1]
+    print(f"  voxels U={U} of M={S * H * W}")
+    _save("recon_tiny", {
+        "latent": lat, "image": img,
+        "pose_enc_list": torch.stack(ref.pred_pose_enc_list), "depth": ref.depth_dict["depth"],
+        "means": gs.means, "scales": gs.scales, "rotations": gs.rotations, "harmonics": gs.harmonics.half(),
+        "opacities": gs.opacities, "c2w": ref.pred_context_pose["extrinsic"], "intrinsic": ref.pred_context_pose["intrinsic"],
+        "scene_scale": ref.infos["scene_scale"].reshape(1),
+    })
+
+
+def voxel_collide():
+    """EncoderAnySplat.voxelizaton_with_fusion on points engineered to collide (several points per voxel, negative
+    coordinates, exact .5 rounding ties): integer keys / inverse / counts are the bit-exact contract."""
+    from third_party_model.anysplat.src.model.encoder.anysplat import EncoderAnySplat
+    from oracle import recon as R
+    g = torch.Generator().manual_seed(51)
+    V, C, H, W = 2, 7, 16, 16
+    base = torch.randint(-6, 6, (V, 3, H, W), generator=g).float() * 0.002
+    jitter = (torch.rand(V, 3, H, W, generator=g) - 0.5) * 0.0019
+    pts = base + jitter
+    pts[0, :, 0, :4] = torch.tensor([0.001, -0.001, 0.003]).view(3, 1)  # exact half-voxel ties (round-half-even)
+    feat = torch.randn(V, C, H, W, generator=g)
+    conf = torch.randn(V, H, W, generator=g) * 2
+    enc = _bare(EncoderAnySplat)
+    with torch.no_grad():
+        rp, rf = enc.voxelizaton_with_fusion(feat, pts, 0.002, conf)
+        vp, vf, keys, inv, cnt = R.voxelize_with_fusion(feat, pts, 0.002, conf)
+    e1, e2 = (rp - vp).abs().max().item(), (rf - vf).abs().max().item()
+    print(f"voxel_collide: U={keys.shape[0]} of M={V * H * W}; max count {cnt.max().item()}; err pts {e1:.2e} feats {e2:.2e}")
+    assert e1 < 1e-6 and e2 < 1e-5 and cnt.max() >= 3
+    _save("voxel_collide", {"pts": pts, "feat": feat, "conf": conf, "voxel_pts": rp, "voxel_feats": rf,
+                            "keys": keys, "inverse": inv.to(torch.int32), "counts": cnt.to(torch.int32)})
+
+
+GENERATORS = {f.__name__: f for f in [vae_decode_tiny, stitch_tiny, recon_tiny, voxel_collide]}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)
