@@ -22,7 +22,7 @@ extern "C" {
 #define V3A_ERR_SHAPE (-2)
 #define V3A_ERR_LAUNCH (-3)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 2) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -48,7 +48,8 @@ enum {
   V3A_GEMM_ROUND_AFTER_SCALE = 1 << 2, /* round v*scale to bf16 before adding the residual */
   V3A_GEMM_RES_F32 = 1 << 3,      /* residual is float32 (aggregator residual stream) else bf16 */
   V3A_GEMM_OUT_F32 = 1 << 4,      /* store float32 else bf16 */
-  V3A_GEMM_NO_ROUND_ACC = 1 << 5  /* skip the bf16 rounding of acc+bias (fp32 heads) — NOTE: staged via bf16 unless OUT_F32 */
+  V3A_GEMM_NO_ROUND_ACC = 1 << 5, /* reserved (not implemented: accumulators are parked as bf16) */
+  V3A_GEMM_RELU_OUT = 1 << 6      /* ReLU after the residual adds (DPT ResidualConvUnit chains) */
 };
 typedef struct {
   const void* A;        /* bf16 [M, lda] */
@@ -63,6 +64,10 @@ typedef struct {
   int act;              /* V3A_ACT_* */
   int flags;            /* V3A_GEMM_* */
   int tile;             /* -1 = auto, else index into the tile table (bench/tuning) */
+  const void* residual2; /* optional second residual, bf16 [M, ldr2] */
+  int ldr2;
+  int res_row_mod;      /* > 0: `residual` row index is (row % res_row_mod): broadcast table (positional embedding) */
+  int out_row_group, out_row_skip, out_row_off; /* group > 0: output row = row + (row / group) * skip + off */
 } v3a_gemm_args;
 int v3a_gemm_bf16_nt(const v3a_gemm_args* args, void* stream);
 int v3a_gemm_num_tiles(void);
@@ -92,6 +97,8 @@ typedef struct {
   int ups2, replicate;
   int ldy, ldr;
   int act, flags, tile;
+  const void* residual2; int ldr2; int res_row_mod;
+  int out_row_group, out_row_skip, out_row_off;   /* as in v3a_gemm_args */
 } v3a_conv_args;
 int v3a_conv_bf16(const v3a_conv_args* args, void* stream);
 
@@ -101,7 +108,7 @@ int v3a_conv_bf16(const v3a_conv_args* args, void* stream);
  *   diffusers==0.33.1 WanAttnProcessor2_0 (DiT self/cross attention; call site inference_t23d.py:94-103)
  *   /root/reference/third_party_model/anysplat/src/model/encoder/vggt/layers/attention.py:64-69
  * Q,K: [B][N][H*D] with row stride ld* ; V is passed TRANSPOSED: vt[(h*D+d)*ldvt + b*vt_batch_stride + key],
- * readable and finite (zero) up to the next multiple of 64 keys.  D in {64,128}.
+ * readable and finite up to the next multiple of 64 keys past each batch's Nk.  D in {64,128}.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   const void* q; const void* k; const void* vt; void* o;   /* bf16 */
@@ -109,6 +116,7 @@ typedef struct {
   int ldq, ldk, ldvt, ldo;                                  /* elements */
   int B, H, Nq, Nk, D;
   float scale;                                              /* softmax scale, normally D^-0.5 */
+  int kv_period, kv_valid;  /* kv_period >= 64: key k participates only if (k % kv_period) < kv_valid (per-frame row padding) */
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 
@@ -125,6 +133,8 @@ typedef struct {
   int rows_per_batch, mod_stride;
   float eps;
   int x_is_f32, y_is_f32;
+  int in_row_group, in_row_skip, in_row_off;    /* group > 0: logical row m reads x row m + (m/group)*skip + off */
+  int out_row_group, out_row_skip, out_row_off; /* same for the output (gather/scatter of per-frame token blocks) */
 } v3a_layernorm_args;
 int v3a_layernorm(const v3a_layernorm_args* args, void* stream);
 
@@ -154,6 +164,42 @@ int v3a_rownorm_act(const v3a_rownorm_args* args, void* stream);
 /* P[M,N] (bf16) = softmax(scale * S[M,N]) (f32), row-wise.  The VAE mid-block's single 384-wide head
  * (/root/reference/utils/wan_utils.py:428-475) runs as GEMM -> this -> GEMM. */
 int v3a_softmax_rows(const float* s, void* p, int M, int N, int lds, int ldp, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stitched-reconstruction glue.  Channels-last (CL) tensors are [T][H][W][C].
+ * ---------------------------------------------------------------------------------------------- */
+/* per-head LayerNorm(64, affine) on q and k + 2-D RoPE, in place on the fused [q|k] buffer qk[M][ld] (q cols 0..C-1,
+ * k cols C..2C-1).  vggt/layers/attention.py:56-61, rope.py:154-188.  cos_sin = f32 [maxpos][16][2]; token row r has
+ * p = r % rows_per_frame; p < n_special or p >= n_valid -> position 0, else patch p-n_special -> (y,x)+1 on a wp-wide grid. */
+int v3a_qknorm_rope2d(void* qk, int M, int ld, int C, const float* q_w, const float* q_b, const float* k_w, const float* k_b,
+                      const float* cos_sin, int rows_per_frame, int n_special, int n_valid, int wp, float eps, void* stream);
+/* latent z[C][Tl][H][W] f32 -> CL bf16 [4(Tl-1)+1][H][W][C], align_corners=True lerp in T (models/stitched_model.py:92-107) */
+int v3a_latent_upsample_t_cl(const float* z, void* y, int C, int Tl, int H, int W, void* stream);
+/* bilinear resize of a CL bf16 stack (+ bf16 addend [T*H*W][C]) (+ f32 table [H*W][C] broadcast over T) (+ ReLU)
+ * vggt/heads/dpt_head.py:460-466 (align_corners=True), inference_t23d.py:118-123 (False) */
+int v3a_bilinear_cl(const void* x, void* y, const void* add, const float* table, int T, int h, int w, int H, int W, int C,
+                    int align_corners, int relu, int out_f32, void* stream);
+/* depth head activation + unprojection: raw[M][ld] f32 (col0 log-depth, col1 log-conf) -> depth[M]=exp, conf[M]=1+exp,
+ * pts[M][3] world points.  cam[S][16] = {fx,fy,cx,cy, R^T (9, row-major), -R^T t (3)}.  head_act.py:61-112, geometry.py:10-58 */
+int v3a_depth_unproject(const float* raw, int ld, const float* cam, float* depth, float* conf, float* pts, int S, int H, int W,
+                        void* stream);
+/* voxel fusion: see csrc/voxel.hip.  feat[M][ldf] f32 holds nfeat feature columns (0..nfeat-1) and the raw confidence at
+ * conf_col.  Outputs sized for the worst case U = M: keys_out[M][3] i32 (lexicographically sorted unique voxel coords),
+ * inverse_out[M] i32, counts_out[M] i32, voxel_pts[M][3], voxel_feat[M][ldo]; *num_voxels = U (device int).
+ * *status (device int) != 0 if a coordinate fell outside [-2^20, 2^20) voxels.  anysplat.py:298-335 */
+long v3a_voxelize_workspace_bytes(long M);
+int v3a_voxelize_fuse(const float* pts, const float* feat, int ldf, int nfeat, int conf_col, long M, float voxel_size,
+                      void* workspace, long workspace_bytes, int* keys_out, int* inverse_out, int* counts_out,
+                      float* voxel_pts, float* voxel_feat, int ldo, int* num_voxels, int* status, void* stream);
+/* UnifiedGaussianAdapter + opacity map: feats[U][ldf] = {density logit, 3 scale, 4 quat xyzw, 3*(deg+1)^2 SH}
+ * common/gaussian_adapter.py:114-147, common/gaussians.py:33-44, anysplat.py:225-238 (opacity_exponent = 2^x) */
+int v3a_gaussian_adapter(const float* pts, const float* feats, int ldf, long U, int sh_degree, float opacity_exponent,
+                         const float* sh_mask, float* means, float* cov, float* sh, float* opac, float* scales, float* rot,
+                         void* stream);
+/* fp32 camera-head primitives (vggt/heads/camera_head.py:87-170): y[M<=32][N] = act(x.W^T + b) * gamma + residual */
+int v3a_linear_f32(const float* x, const float* w, const float* bias, float* y, const float* residual, const float* gamma,
+                   int M, int N, int K, int ldx, int ldy, int ldr, int act, void* stream);
+int v3a_attention_small_f32(const float* qkv, float* out, int S, int H, int hd, float scale, void* stream);
 
 #ifdef __cplusplus
 }

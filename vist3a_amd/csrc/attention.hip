@@ -31,6 +31,7 @@ struct AttnP {
   int ldq, ldk, ldvt, ldo;        // row strides (elements)
   int H, Nq, Nk;
   float scale_log2e;              // softmax scale * log2(e)
+  int kv_period, kv_valid;        // kv_period > 0: key k takes part only if (k % kv_period) < kv_valid
 };
 
 template <int D, int NW>
@@ -169,6 +170,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnP p) {
         for (int r = 0; r < 16; ++r)
           if (kb + 32 * t + r >= p.Nk) s[t][r] = -1e30f;
     }
+    if (p.kv_period > 0) {  // padded multi-frame token layout: mask the per-frame filler rows
+      const int pos = (kt * KV) % p.kv_period;
+      if (pos + KV > p.kv_valid) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int o = pos + 32 * t + 16 * hi + r;
+            o = o >= p.kv_period ? o - p.kv_period : o;
+            if (o >= p.kv_valid) s[t][r] = -1e30f;
+          }
+      }
+    }
     float mx = s[0][0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
@@ -276,13 +290,15 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   if (a->q_batch_stride % 8 || a->k_batch_stride % 8 || a->vt_batch_stride % 8 || a->o_batch_stride % 8)
     return V3A_ERR_SHAPE;
   // V^T rows must be readable (and finite, ideally zero) up to the next multiple of 64 keys
-  if (a->vt_batch_stride && a->vt_batch_stride < ((a->Nk + 63) / 64) * 64 && a->B > 1) return V3A_ERR_SHAPE;
+  if (a->vt_batch_stride && a->vt_batch_stride < a->Nk && a->B > 1) return V3A_ERR_SHAPE;
+  if (a->kv_period < 0 || (a->kv_period > 0 && (a->kv_period < 64 || a->kv_valid <= 0 || a->kv_valid > a->kv_period))) return V3A_ERR_ARG;
   AttnP p;
   p.q = (const char*)a->q; p.k = (const char*)a->k; p.vt = (const char*)a->vt; p.o = (char*)a->o;
   p.q_bs = a->q_batch_stride; p.k_bs = a->k_batch_stride; p.vt_bs = a->vt_batch_stride; p.o_bs = a->o_batch_stride;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;
   p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
   p.scale_log2e = a->scale * 1.4426950408889634f;
+  p.kv_period = a->kv_period; p.kv_valid = a->kv_valid;
   if (a->D == 128) return launch_attn<128, 4>(p, a->B, stream);
   return launch_attn<64, 4>(p, a->B, stream);
 }

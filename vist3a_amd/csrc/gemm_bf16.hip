@@ -30,6 +30,9 @@ struct GemmP {
   int lda, ldb, ldc, ldr;  // in elements
   int rpb, sstride;
   int act, flags;
+  const char* res2;        // optional second residual (bf16), added after `res`
+  int ldr2, res_mod;       // res_mod > 0: residual row = m % res_mod (broadcast table, e.g. positional embedding)
+  int orow_group, orow_skip, orow_off;  // orow_group > 0: output row = m + (m / group) * skip + off
   // implicit-GEMM convolution (CONV instantiations only): A is a channels-last activation [T][H][W][Cin]
   const int* ktab;        // one packed entry per 8-channel K chunk: cin | dw<<16 | dh<<20 | dt<<24 | valid<<31
   int cT, cH, cW, cCin;   // input extent
@@ -269,28 +272,41 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
       }
     }
     if (p.res) {
+      const int mr = p.res_mod > 0 ? m % p.res_mod : m;
       if (flags & V3A_GEMM_RES_F32) {
-        const float* rp = (const float*)p.res + (size_t)m * p.ldr + n;
+        const float* rp = (const float*)p.res + (size_t)mr * p.ldr + n;
         const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
       } else {
-        const u32x4 rr = *(const u32x4*)(p.res + ((size_t)m * p.ldr + n) * 2);
+        const u32x4 rr = *(const u32x4*)(p.res + ((size_t)mr * p.ldr + n) * 2);
         float rf[8];
         unpack_bf16x8(rr, rf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rf[e];
       }
     }
+    if (p.res2) {
+      const u32x4 rr = *(const u32x4*)(p.res2 + ((size_t)m * p.ldr2 + n) * 2);
+      float rf[8];
+      unpack_bf16x8(rr, rf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rf[e];
+    }
+    if (flags & V3A_GEMM_RELU_OUT) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    const size_t mo = p.orow_group > 0 ? (size_t)m + (size_t)(m / p.orow_group) * p.orow_skip + p.orow_off : (size_t)m;
     if (flags & V3A_GEMM_OUT_F32) {
-      float* cp = (float*)p.C + (size_t)m * p.ldc + n;
+      float* cp = (float*)p.C + mo * p.ldc + n;
       f32x4 o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
       *(f32x4*)cp = o0;
       *(f32x4*)(cp + 4) = o1;
     } else {
-      *(u32x4*)(p.C + ((size_t)m * p.ldc + n) * 2) = pack_bf16x8(v);
+      *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = pack_bf16x8(v);
     }
   }
 }
@@ -372,6 +388,9 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : 1; p.sstride = a->scale_stride;
   p.act = a->act; p.flags = a->flags;
+  p.res2 = (const char*)a->residual2; p.ldr2 = a->ldr2; p.res_mod = a->res_row_mod;
+  p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
+  if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
   return launch(p, a->tile, false, stream);
 }
 
@@ -396,5 +415,8 @@ extern "C" int v3a_conv_bf16(const v3a_conv_args* a, void* stream) {
   p.sT = a->sT; p.sH = a->sH; p.sW = a->sW;
   p.pT = a->pT; p.pH = a->pH; p.pW = a->pW;
   p.ups = a->ups2 ? 1 : 0; p.replicate = a->replicate ? 1 : 0;
+  p.res2 = (const char*)a->residual2; p.ldr2 = a->ldr2; p.res_mod = a->res_row_mod;
+  p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
+  if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
   return launch(p, a->tile, true, stream);
 }

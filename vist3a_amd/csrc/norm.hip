@@ -18,13 +18,16 @@ struct LnP {
   int rpb, mstride;
   float eps;
   int x_f32, y_f32;
+  int ig, is, io, og, os, oo;   // row remaps: in row = m + (m/ig)*is + io (ig>0), out row likewise
 };
 
 template <int CPL>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= p.M) return;
+  const int row0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row0 >= p.M) return;
+  const size_t row = p.ig > 0 ? (size_t)row0 + (size_t)(row0 / p.ig) * p.is + p.io : (size_t)row0;
+  const size_t orow = p.og > 0 ? (size_t)row0 + (size_t)(row0 / p.og) * p.os + p.oo : (size_t)row0;
   const int nch = p.d >> 3;
   float v[CPL][8];
   float sum = 0.f;
@@ -33,12 +36,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
     const int c = lane + i * 64;
     if (c < nch) {
       if (p.x_f32) {
-        const float* xp = (const float*)p.x + (size_t)row * p.ldx + c * 8;
+        const float* xp = (const float*)p.x + row * p.ldx + c * 8;
         const f32x4 a = *(const f32x4*)xp, bq = *(const f32x4*)(xp + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = bq[e]; }
       } else {
-        const u32x4 raw = *(const u32x4*)(p.x + ((size_t)row * p.ldx + c * 8) * 2);
+        const u32x4 raw = *(const u32x4*)(p.x + (row * p.ldx + c * 8) * 2);
         unpack_bf16x8(raw, v[i]);
       }
 #pragma unroll
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
     }
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)p.d + p.eps);
-  const size_t moff = (size_t)(row / p.rpb) * p.mstride;
+  const size_t moff = (size_t)(row0 / p.rpb) * p.mstride;
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
     const int c = lane + i * 64;
@@ -76,14 +79,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
       for (int e = 0; e < 8; ++e) o[e] = o[e] * (1.f + p.scale[moff + c * 8 + e]) + p.shift[moff + c * 8 + e];
     }
     if (p.y_f32) {
-      float* yp = (float*)p.y + (size_t)row * p.ldy + c * 8;
+      float* yp = (float*)p.y + orow * p.ldy + c * 8;
       f32x4 a, bq;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { a[e] = o[e]; bq[e] = o[4 + e]; }
       *(f32x4*)yp = a;
       *(f32x4*)(yp + 4) = bq;
     } else {
-      *(u32x4*)(p.y + ((size_t)row * p.ldy + c * 8) * 2) = pack_bf16x8(o);
+      *(u32x4*)(p.y + (orow * p.ldy + c * 8) * 2) = pack_bf16x8(o);
     }
   }
 }
@@ -253,6 +256,8 @@ extern "C" int v3a_layernorm(const v3a_layernorm_args* a, void* stream) {
   p.M = a->M; p.d = a->d; p.ldx = a->ldx; p.ldy = a->ldy;
   p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : a->M; p.mstride = a->mod_stride;
   p.eps = a->eps; p.x_f32 = a->x_is_f32; p.y_f32 = a->y_is_f32;
+  p.ig = a->in_row_group; p.is = a->in_row_skip; p.io = a->in_row_off;
+  p.og = a->out_row_group; p.os = a->out_row_skip; p.oo = a->out_row_off;
   const dim3 grid((a->M + 3) / 4);
   DISPATCH_CPL(layernorm_kernel, p, a->d, grid, stream);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;

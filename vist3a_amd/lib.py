@@ -19,6 +19,7 @@ GEMM_SCALE_PER_BATCH = 1 << 1
 GEMM_ROUND_AFTER_SCALE = 1 << 2
 GEMM_RES_F32 = 1 << 3
 GEMM_OUT_F32 = 1 << 4
+GEMM_RELU_OUT = 1 << 6
 
 
 class GemmArgs(C.Structure):
@@ -29,6 +30,8 @@ class GemmArgs(C.Structure):
         ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
         ("rows_per_batch", C.c_int), ("scale_stride", C.c_int),
         ("act", C.c_int), ("flags", C.c_int), ("tile", C.c_int),
+        ("residual2", C.c_void_p), ("ldr2", C.c_int), ("res_row_mod", C.c_int),
+        ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
     ]
 
 
@@ -43,6 +46,8 @@ class ConvArgs(C.Structure):
         ("ups2", C.c_int), ("replicate", C.c_int),
         ("ldy", C.c_int), ("ldr", C.c_int),
         ("act", C.c_int), ("flags", C.c_int), ("tile", C.c_int),
+        ("residual2", C.c_void_p), ("ldr2", C.c_int), ("res_row_mod", C.c_int),
+        ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
     ]
 
 
@@ -53,7 +58,7 @@ class AttnArgs(C.Structure):
         ("vt_batch_stride", C.c_long), ("o_batch_stride", C.c_long),
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("kv_period", C.c_int), ("kv_valid", C.c_int),
     ]
 
 
@@ -66,6 +71,8 @@ class LayerNormArgs(C.Structure):
         ("rows_per_batch", C.c_int), ("mod_stride", C.c_int),
         ("eps", C.c_float),
         ("x_is_f32", C.c_int), ("y_is_f32", C.c_int),
+        ("in_row_group", C.c_int), ("in_row_skip", C.c_int), ("in_row_off", C.c_int),
+        ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
     ]
 
 
@@ -99,6 +106,16 @@ SYMBOLS = {
     "v3a_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "v3a_rmsnorm_rope": (C.c_int, [C.POINTER(RmsNormRopeArgs), C.c_void_p]),
     "v3a_rownorm_act": (C.c_int, [C.POINTER(RowNormArgs), C.c_void_p]),
+    "v3a_qknorm_rope2d": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "v3a_latent_upsample_t_cl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "v3a_bilinear_cl": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 9 + [C.c_void_p]),
+    "v3a_depth_unproject": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
+    "v3a_voxelize_workspace_bytes": (C.c_long, [C.c_long]),
+    "v3a_voxelize_fuse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float, C.c_void_p, C.c_long]
+                          + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v3a_gaussian_adapter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_float] + [C.c_void_p] * 8),
+    "v3a_linear_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
+    "v3a_attention_small_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "v3a_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
 }
 

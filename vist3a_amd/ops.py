@@ -46,8 +46,13 @@ def gemm(
     out_f32: bool = False,
     bias_row: bool = False,
     tile: int = -1,
+    residual2: Optional[torch.Tensor] = None,
+    res_row_mod: int = 0,
+    relu_out: bool = False,
+    out_rows: Optional[tuple] = None,
 ) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T); see v3a_gemm_bf16_nt for the epilogue order.
+    out_rows=(group, skip, off) scatters output row m to m + (m//group)*skip + off (out must be given).
 
     scale: f32 [N] (LayerScale) or [nbatch, N] together with rows_per_batch (AdaLN gate)."""
     _chk2d(a, "a", (bf16,))
@@ -57,9 +62,11 @@ def gemm(
     if K != K2:
         raise ValueError(f"K mismatch: a {tuple(a.shape)} vs w {tuple(w.shape)}")
     if out is None:
+        if out_rows is not None:
+            raise ValueError("out_rows needs an explicit out tensor")
         out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
     _chk2d(out, "out", (f32,) if out_f32 else (bf16,))
-    flags = 0
+    flags = L.GEMM_RELU_OUT if relu_out else 0
     if bias is not None:
         if bias.dtype != f32 or not bias.is_contiguous() or bias.numel() != (M if bias_row else N):
             raise ValueError("bias must be contiguous f32 of length N (or M with bias_row)")
@@ -79,7 +86,7 @@ def gemm(
     ldr = 0
     if residual is not None:
         _chk2d(residual, "residual", (bf16, f32))
-        if residual.shape != (M, N):
+        if residual.shape[1] != N or (res_row_mod == 0 and residual.shape[0] != M):
             raise ValueError("residual shape mismatch")
         if residual.dtype == f32:
             flags |= L.GEMM_RES_F32
@@ -90,6 +97,8 @@ def gemm(
         _ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(scale),
         M, N, K, a.stride(0), w.stride(0), out.stride(0), ldr,
         rows_per_batch, sstride, act, flags, tile,
+        _ptr(residual2), residual2.stride(0) if residual2 is not None else 0, res_row_mod,
+        *(out_rows if out_rows is not None else (0, 0, 0)),
     )
     L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")
     return out
@@ -133,7 +142,8 @@ def conv(
     x: torch.Tensor, cw: ConvWeight, *, out: Optional[torch.Tensor] = None,
     stride=(1, 1, 1), pad=(0, 0, 0), out_size=None, ups2: bool = False, replicate: bool = False,
     act: int = L.ACT_NONE, residual: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
-    out_f32: bool = False, tile: int = -1,
+    out_f32: bool = False, tile: int = -1, residual2: Optional[torch.Tensor] = None, res_row_mod: int = 0,
+    relu_out: bool = False, out_rows: Optional[tuple] = None,
 ) -> torch.Tensor:
     """x: channels-last [T,H,W,CinP] bf16 contiguous -> out [oT,oH,oW,CoutP].  pad = LEADING pad per dim.  Spatial
     dims follow PyTorch's symmetric-pad formula; the temporal dim is causal (all padding leading) when
@@ -157,12 +167,12 @@ def conv(
     M = oT * oH * oW
     if out is None:
         out = torch.empty((oT, oH, oW, cw.CoutP), device=x.device, dtype=f32 if out_f32 else bf16)
-    o2 = out.view(M, out.shape[-1])
-    flags = 0
+    o2 = out.view(-1, out.shape[-1])
+    flags = L.GEMM_RELU_OUT if relu_out else 0
     ldr = 0
     r2 = None
     if residual is not None:
-        r2 = residual.view(M, residual.shape[-1])
+        r2 = residual.view(-1, residual.shape[-1])
         if r2.dtype == f32:
             flags |= L.GEMM_RES_F32
         ldr = r2.stride(0)
@@ -173,6 +183,8 @@ def conv(
         T, H, W, Cin, oT, oH, oW, cw.CoutP, cw.Kpad,
         stride[0], stride[1], stride[2], pad[0], pad[1], pad[2],
         int(ups2), int(replicate), o2.stride(0), ldr, act, flags, tile,
+        _ptr(residual2), residual2.view(-1, residual2.shape[-1]).stride(0) if residual2 is not None else 0, res_row_mod,
+        *(out_rows if out_rows is not None else (0, 0, 0)),
     )
     L.check(L.load().v3a_conv_bf16(C.byref(args), _stream()), "v3a_conv_bf16")
     return out
@@ -182,7 +194,7 @@ def attention(
     q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *,
     B: int, H: int, Nq: int, Nk: int, D: int,
     q_batch_stride: int, k_batch_stride: int, vt_batch_stride: int, o_batch_stride: int,
-    scale: Optional[float] = None,
+    scale: Optional[float] = None, kv_period: int = 0, kv_valid: int = 0,
 ) -> torch.Tensor:
     """q,k,out: 2-D views [B*N, >=H*D] (row stride = their stride(0)); vt: 2-D [H*D, >=B*vt_batch_stride]."""
     for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (out, "out")):
@@ -191,7 +203,7 @@ def attention(
         _ptr(q), _ptr(k), _ptr(vt), _ptr(out),
         q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride,
         q.stride(0), k.stride(0), vt.stride(0), out.stride(0),
-        B, H, Nq, Nk, D, float(scale if scale is not None else D ** -0.5),
+        B, H, Nq, Nk, D, float(scale if scale is not None else D ** -0.5), kv_period, kv_valid,
     )
     L.check(L.load().v3a_attention_fwd_bf16(C.byref(args), _stream()), "v3a_attention_fwd_bf16")
     return out
@@ -202,9 +214,13 @@ def layernorm(
     weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
     scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
     rows_per_batch: int = 0, eps: float = 1e-6, out_dtype: torch.dtype = bf16,
+    M: Optional[int] = None, in_rows: tuple = (0, 0, 0), out_rows: tuple = (0, 0, 0),
 ) -> torch.Tensor:
+    """in_rows/out_rows = (group, skip, off): logical row m maps to physical row m + (m//group)*skip + off."""
     _chk2d(x, "x", (bf16, f32))
-    M, d = x.shape
+    d = x.shape[1]
+    if M is None:
+        M = x.shape[0]
     if out is None:
         out = torch.empty((M, d), device=x.device, dtype=out_dtype)
     _chk2d(out, "out", (bf16, f32))
@@ -221,7 +237,7 @@ def layernorm(
     args = L.LayerNormArgs(
         _ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(scale), _ptr(shift),
         M, d, x.stride(0), out.stride(0), rows_per_batch, mstride, eps,
-        int(x.dtype == f32), int(out.dtype == f32),
+        int(x.dtype == f32), int(out.dtype == f32), *in_rows, *out_rows,
     )
     L.check(L.load().v3a_layernorm(C.byref(args), _stream()), "v3a_layernorm")
     return out
@@ -272,4 +288,105 @@ def softmax_rows(s: torch.Tensor, scale: float, out: Optional[torch.Tensor] = No
     _chk2d(out, "out", (bf16,))
     L.check(L.load().v3a_softmax_rows(_ptr(s), _ptr(out), M, N, s.stride(0), out.stride(0), float(scale), _stream()),
             "v3a_softmax_rows")
+    return out
+
+
+def qknorm_rope2d(qk: torch.Tensor, C: int, qw, qb, kw, kb, cos_sin: Optional[torch.Tensor], rows_per_frame: int,
+                  n_special: int, n_valid: int, wp: int, eps: float = 1e-5) -> torch.Tensor:
+    _chk2d(qk, "qk", (bf16,))
+    L.check(L.load().v3a_qknorm_rope2d(_ptr(qk), qk.shape[0], qk.stride(0), C, _ptr(qw), _ptr(qb), _ptr(kw), _ptr(kb),
+                                       _ptr(cos_sin), rows_per_frame, n_special, n_valid, wp, eps, _stream()), "v3a_qknorm_rope2d")
+    return qk
+
+
+def latent_upsample_t_cl(z: torch.Tensor) -> torch.Tensor:
+    """z [C,Tl,H,W] f32 contiguous -> [4(Tl-1)+1,H,W,C] bf16."""
+    if z.dtype != f32 or not z.is_contiguous() or z.dim() != 4:
+        raise ValueError("z must be contiguous f32 [C,Tl,H,W]")
+    Cc, Tl, H, W = z.shape
+    out = torch.empty(((Tl - 1) * 4 + 1, H, W, Cc), device=z.device, dtype=bf16)
+    L.check(L.load().v3a_latent_upsample_t_cl(_ptr(z), _ptr(out), Cc, Tl, H, W, _stream()), "v3a_latent_upsample_t_cl")
+    return out
+
+
+def bilinear_cl(x: torch.Tensor, size, *, align_corners: bool, add: Optional[torch.Tensor] = None,
+                table: Optional[torch.Tensor] = None, relu: bool = False, out_f32: bool = False) -> torch.Tensor:
+    if x.dtype != bf16 or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError("x must be contiguous bf16 [T,h,w,C]")
+    T, h, w, Cc = x.shape
+    H, W = size
+    out = torch.empty((T, H, W, Cc), device=x.device, dtype=f32 if out_f32 else bf16)
+    if add is not None and (add.dtype != bf16 or not add.is_contiguous() or add.numel() != out.numel()):
+        raise ValueError("add must be contiguous bf16 with the output's shape")
+    if table is not None and (table.dtype != f32 or not table.is_contiguous() or table.numel() != H * W * Cc):
+        raise ValueError("table must be contiguous f32 [H*W, C]")
+    L.check(L.load().v3a_bilinear_cl(_ptr(x), _ptr(out), _ptr(add), _ptr(table), T, h, w, H, W, Cc, int(align_corners), int(relu),
+                                     int(out_f32), _stream()), "v3a_bilinear_cl")
+    return out
+
+
+def depth_unproject(raw: torch.Tensor, cam: torch.Tensor, S: int, H: int, W: int):
+    """raw [S*H*W, ld] f32, cam [S,16] f32 -> depth [S,H,W], conf [S,H,W], pts [S,H,W,3] (all f32)."""
+    _chk2d(raw, "raw", (f32,))
+    dev = raw.device
+    depth = torch.empty(S, H, W, device=dev, dtype=f32)
+    conf = torch.empty(S, H, W, device=dev, dtype=f32)
+    pts = torch.empty(S, H, W, 3, device=dev, dtype=f32)
+    L.check(L.load().v3a_depth_unproject(_ptr(raw), raw.stride(0), _ptr(cam.contiguous()), _ptr(depth), _ptr(conf), _ptr(pts), S, H, W,
+                                         _stream()), "v3a_depth_unproject")
+    return depth, conf, pts
+
+
+def voxelize_fuse(pts: torch.Tensor, feat: torch.Tensor, nfeat: int, conf_col: int, voxel_size: float):
+    """pts [M,3] f32, feat [M,ld] f32 -> dict(voxel_pts [U,3], voxel_feat [U,nfeat], keys [U,3] i32, inverse [M] i32, counts [U] i32)."""
+    _chk2d(pts, "pts", (f32,))
+    _chk2d(feat, "feat", (f32,))
+    M, dev = pts.shape[0], pts.device
+    lib = L.load()
+    ws = torch.empty(int(lib.v3a_voxelize_workspace_bytes(M)), device=dev, dtype=torch.uint8)
+    keys = torch.empty(M, 3, device=dev, dtype=torch.int32)
+    inv = torch.empty(M, device=dev, dtype=torch.int32)
+    cnt = torch.empty(M, device=dev, dtype=torch.int32)
+    vp = torch.empty(M, 3, device=dev, dtype=f32)
+    vf = torch.empty(M, nfeat, device=dev, dtype=f32)
+    meta = torch.zeros(2, device=dev, dtype=torch.int32)
+    L.check(lib.v3a_voxelize_fuse(_ptr(pts.contiguous()), _ptr(feat), feat.stride(0), nfeat, conf_col, M, float(voxel_size), _ptr(ws), ws.numel(),
+                                  _ptr(keys), _ptr(inv), _ptr(cnt), _ptr(vp), _ptr(vf), nfeat, C.c_void_p(meta.data_ptr()),
+                                  C.c_void_p(meta.data_ptr() + 4), _stream()), "v3a_voxelize_fuse")
+    U, bad = (int(v) for v in meta.tolist())  # one host sync: the Gaussian count sizes every downstream tensor
+    if bad:
+        raise RuntimeError("voxel coordinate outside [-2^20, 2^20): points too far for the 63-bit key")
+    return dict(voxel_pts=vp[:U], voxel_feat=vf[:U], keys=keys[:U], inverse=inv, counts=cnt[:U])
+
+
+def gaussian_adapter(pts: torch.Tensor, feats: torch.Tensor, sh_mask: torch.Tensor, sh_degree: int = 4, opacity_exponent: float = 1.0):
+    _chk2d(feats, "feats", (f32,))
+    U, dev, dsh = feats.shape[0], feats.device, (sh_degree + 1) ** 2
+    e = lambda *s: torch.empty(*s, device=dev, dtype=f32)
+    means, cov, sh, op, sc, rot = e(U, 3), e(U, 3, 3), e(U, 3, dsh), e(U), e(U, 3), e(U, 4)
+    L.check(L.load().v3a_gaussian_adapter(_ptr(pts.contiguous()), _ptr(feats), feats.stride(0), U, sh_degree, float(opacity_exponent),
+                                          _ptr(sh_mask), _ptr(means), _ptr(cov), _ptr(sh), _ptr(op), _ptr(sc), _ptr(rot), _stream()),
+            "v3a_gaussian_adapter")
+    return dict(means=means, covariances=cov, harmonics=sh, opacities=op, scales=sc, rotations=rot)
+
+
+def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
+               residual: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk2d(x, "x", (f32,))
+    _chk2d(w, "w", (f32,))
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=f32)
+    L.check(L.load().v3a_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(residual), _ptr(gamma), M, N, K, x.stride(0), N,
+                                    residual.stride(0) if residual is not None else 0, act, _stream()), "v3a_linear_f32")
+    return y
+
+
+def attention_small_f32(qkv: torch.Tensor, H: int) -> torch.Tensor:
+    _chk2d(qkv, "qkv", (f32,))
+    S, C3 = qkv.shape
+    Cc = C3 // 3
+    out = torch.empty(S, Cc, device=qkv.device, dtype=f32)
+    hd = Cc // H
+    L.check(L.load().v3a_attention_small_f32(_ptr(qkv.contiguous()), _ptr(out), S, H, hd, hd ** -0.5, _stream()), "v3a_attention_small_f32")
     return out
