@@ -116,7 +116,7 @@ typedef struct {
   int ldq, ldk, ldvt, ldo;                                  /* elements */
   int B, H, Nq, Nk, D;
   float scale;                                              /* softmax scale, normally D^-0.5 */
-  int kv_period, kv_valid;  /* kv_period >= 64: key k participates only if (k % kv_period) < kv_valid (per-frame row padding) */
+  int kv_period, kv_valid;  /* kv_period > 0: key k participates only if (k % kv_period) < kv_valid (per-frame row padding) */
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 

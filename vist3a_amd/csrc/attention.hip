@@ -172,13 +172,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnP p) {
     }
     if (p.kv_period > 0) {  // padded multi-frame token layout: mask the per-frame filler rows
       const int pos = (kt * KV) % p.kv_period;
-      if (pos + KV > p.kv_valid) {
+      if (pos + KV > p.kv_valid) {  // some key of this tile is filler (always true for periods < 64)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            int o = pos + 32 * t + 16 * hi + r;
-            o = o >= p.kv_period ? o - p.kv_period : o;
+            const int o = (pos + 32 * t + 16 * hi + r) % p.kv_period;
             if (o >= p.kv_valid) s[t][r] = -1e30f;
           }
       }
@@ -291,7 +290,7 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
     return V3A_ERR_SHAPE;
   // V^T rows must be readable (and finite, ideally zero) up to the next multiple of 64 keys
   if (a->vt_batch_stride && a->vt_batch_stride < a->Nk && a->B > 1) return V3A_ERR_SHAPE;
-  if (a->kv_period < 0 || (a->kv_period > 0 && (a->kv_period < 64 || a->kv_valid <= 0 || a->kv_valid > a->kv_period))) return V3A_ERR_ARG;
+  if (a->kv_period < 0 || (a->kv_period > 0 && (a->kv_valid <= 0 || a->kv_valid > a->kv_period))) return V3A_ERR_ARG;
   AttnP p;
   p.q = (const char*)a->q; p.k = (const char*)a->k; p.vt = (const char*)a->vt; p.o = (char*)a->o;
   p.q_bs = a->q_batch_stride; p.k_bs = a->k_batch_stride; p.vt_bs = a->vt_batch_stride; p.o_bs = a->o_batch_stride;
