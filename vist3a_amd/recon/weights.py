@@ -1,0 +1,133 @@
+"""Weight sources for the stitched AnySplat encoder: seeded synthetic weights of the exact production shapes under the
+reference's parameter names (no checkpoint is reachable offline), a loader for real `lhjiang/anysplat`
+safetensors, and the LoRA merge that `.eval()` performs in the reference (utils/lora_util/layers.py:161-165)."""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from .engine import ReconCfg
+
+SD = Dict[str, torch.Tensor]
+
+
+def random_recon_state_dict(cfg: ReconCfg, seed: int = 0, device="cpu", n_pos: int = 1370, n_reg: int = 4) -> SD:
+    """Linear/Conv ~ N(0, 1/fan_in) (keeps activations O(1) through 70 blocks), norm gamma ~ 1, LayerScale as the
+    reference initialises it (DINO 1.0, aggregator / camera head 0.01), tokens ~ N(0, 0.02)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rn = lambda *s, std=1.0: torch.randn(*s, generator=g, device=device) * std
+    sd: SD = {}
+
+    def lin(name, o, i):
+        sd[name + ".weight"] = rn(o, i, std=1 / math.sqrt(i))
+        sd[name + ".bias"] = rn(o, std=0.02)
+
+    def block(p, C, heads, qk_norm, ls):
+        for n in ("norm1", "norm2"):
+            sd[p + n + ".weight"] = 1 + rn(C, std=0.05)
+            sd[p + n + ".bias"] = rn(C, std=0.02)
+        lin(p + "attn.qkv", 3 * C, C)
+        lin(p + "attn.proj", C, C)
+        if qk_norm:
+            for n in ("q_norm", "k_norm"):
+                sd[p + f"attn.{n}.weight"] = 1 + rn(C // heads, std=0.05)
+                sd[p + f"attn.{n}.bias"] = rn(C // heads, std=0.02)
+        lin(p + "mlp.fc1", 4 * C, C)
+        lin(p + "mlp.fc2", C, 4 * C)
+        sd[p + "ls1.gamma"] = torch.full((C,), ls, device=device)
+        sd[p + "ls2.gamma"] = torch.full((C,), ls, device=device)
+
+    C = cfg.C
+    a = "encoder.aggregator."
+    pe = a + "patch_embed."
+    sd[pe + "cls_token"] = rn(1, 1, C, std=0.02)
+    sd[pe + "register_tokens"] = rn(1, n_reg, C, std=0.02)
+    sd[pe + "mask_token"] = torch.zeros(1, C, device=device)
+    sd[pe + "pos_embed"] = rn(1, n_pos, C, std=0.02)
+    for i in range(cfg.n_dino):
+        block(pe + f"blocks.{i}.", C, cfg.heads, False, 1.0)
+    sd[pe + "norm.weight"] = 1 + rn(C, std=0.05)
+    sd[pe + "norm.bias"] = rn(C, std=0.02)
+    sd[a + "camera_token"] = rn(1, 2, 1, C, std=0.02)
+    sd[a + "register_token"] = rn(1, 2, n_reg, C, std=0.02)
+    for i in range(cfg.depth):
+        block(a + f"frame_blocks.{i}.", C, cfg.heads, True, 0.01)
+        block(a + f"global_blocks.{i}.", C, cfg.heads, True, 0.01)
+    c, C2 = "encoder.camera_head.", 2 * C
+    for j in range(cfg.cam_trunk):
+        block(c + f"trunk.{j}.", C2, cfg.cam_heads, False, 0.01)
+    for n in ("token_norm", "trunk_norm"):
+        sd[c + n + ".weight"] = 1 + rn(C2, std=0.05)
+        sd[c + n + ".bias"] = rn(C2, std=0.02)
+    sd[c + "empty_pose_tokens"] = torch.zeros(1, 1, 9, device=device)
+    lin(c + "embed_pose", C2, 9)
+    lin(c + "poseLN_modulation.1", 3 * C2, C2)
+    lin(c + "pose_branch.fc1", C2 // 2, C2)
+    lin(c + "pose_branch.fc2", 9, C2 // 2)
+    sd[c + "pose_branch.fc2.weight"] *= 0.1
+
+    def conv(name, o, i, k, bias=True, tr=False):
+        shape = (i, o, k, k) if tr else (o, i, k, k)
+        sd[name + ".weight"] = rn(*shape, std=1 / math.sqrt(i * k * k))
+        if bias:
+            sd[name + ".bias"] = rn(o, std=0.02)
+
+    def dpt(p, features, out_dim, gs):
+        sd[p + "norm.weight"] = 1 + rn(C2, std=0.05)
+        sd[p + "norm.bias"] = rn(C2, std=0.02)
+        for i, oc in enumerate(cfg.oc):
+            conv(p + f"projects.{i}", oc, C2, 1)
+        conv(p + "resize_layers.0", cfg.oc[0], cfg.oc[0], 4, tr=True)
+        conv(p + "resize_layers.1", cfg.oc[1], cfg.oc[1], 2, tr=True)
+        conv(p + "resize_layers.3", cfg.oc[3], cfg.oc[3], 3)
+        s = p + "scratch."
+        for i, oc in enumerate(cfg.oc):
+            conv(s + f"layer{i + 1}_rn", features, oc, 3, bias=False)
+        for r in (1, 2, 3, 4):
+            q = s + f"refinenet{r}."
+            conv(q + "out_conv", features, features, 1)
+            for u in (("resConfUnit1.", "resConfUnit2.") if r != 4 else ("resConfUnit2.",)):
+                conv(q + u + "conv1", features, features, 3)
+                conv(q + u + "conv2", features, features, 3)
+        conv(s + "output_conv1", features // 2, features, 3)
+        if gs:
+            hf2 = 128 if out_dim > 50 else 32
+            conv(p + "input_merger.0", hf2, 3, 7)
+            conv(s + "output_conv2.0", hf2, 128, 3)
+            conv(s + "output_conv2.2", out_dim, hf2, 1)
+        else:
+            conv(s + "output_conv2.0", 32, features // 2, 3)
+            conv(s + "output_conv2.2", out_dim, 32, 1)
+        sd[s + "output_conv2.2.weight"] *= 0.3
+
+    dpt("encoder.depth_head.", cfg.features, 2, False)
+    dpt("encoder.gaussian_param_head.", 256, 1 + 7 + 3 * (cfg.sh_degree + 1) ** 2 + 1, True)
+    return sd
+
+
+def round_aggregator_to_bf16(sd: SD) -> SD:
+    """EncoderAnySplat stores the whole aggregator in bf16 (anysplat.py:144): make the values bf16-representable."""
+    for k in list(sd):
+        if k.startswith("encoder.aggregator."):
+            sd[k] = sd[k].to(torch.bfloat16).to(sd[k].dtype)
+    return sd
+
+
+def merge_lora(sd: SD, lora_sd: SD, alpha: float, r: int) -> int:
+    """loralib-style adapters saved by /root/reference/model_stitching_training.py:59-72 (`…lora_A` [r,in], `…lora_B` [out,r];
+    Conv2d: lora_A [r*k, in*k], lora_B [out*k, r*k] reshaped to the conv weight).  W += (B @ A).view_as(W) * alpha / r —
+    what Linear.train(False) / ConvLoRA.train(False) do when the reference calls .eval() (lora_util/layers.py:149-165,338-355)."""
+    n = 0
+    for key, A in lora_sd.items():
+        if not key.endswith("lora_A"):
+            continue
+        base = key[: -len("lora_A")]
+        B = lora_sd.get(base + "lora_B")
+        w = base + "weight"
+        if B is None or w not in sd:
+            continue
+        sd[w] = (sd[w].float() + (B.float() @ A.float()).view(sd[w].shape) * (alpha / r)).to(sd[w].dtype)
+        n += 1
+    return n
