@@ -1,0 +1,156 @@
+"""Headline benchmark: 3D-Gaussian scenes/sec — 50-step CFG denoise (Wan-1.3B DiT + UniPC) -> Wan VAE decode -> 512->448
+resize -> stitched Conv3d -> AnySplat reconstruction (13 views @512), synthetic inputs and seeded random weights of the
+production shapes (BASELINE.json configs[1]; no checkpoint is reachable offline).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one complete scene.  N>1 = data parallel over prompts exactly like the reference (prompt_list[rank::world],
+/root/reference/inference_t23d.py:62): every rank owns whole scenes, no data-path collective (weak scaling).
+Rank 0 prints ONE JSON line (contract in the task statement) incl. `roofline` for the dominant kernel and `cpu_baseline`."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import torch
+
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def dit_flops_per_forward(N, d, ffn, L, ctx=512):
+    """projections + attention + FFN, multiply-add = 2."""
+    return L * (8 * N * d * d + 4 * N * N * d + (4 * N * d * d + 4 * ctx * d * d) + 4 * N * ctx * d + 4 * N * d * ffn)
+
+
+def cpu_baseline(cfg, seconds_budget: float):
+    """Oracle (CPU fp32 restatement) timed on the host cores on a bounded sample: ONE full-size (N=4096, B=1) DiT forward
+    restricted to 2 of the 30 blocks; extrapolated to 30 blocks x 100 forwards.  VAE+recon (5 % of the FLOPs) excluded."""
+    from oracle import wan_dit as O
+    ocfg = O.WanDiTConfig(num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim, ffn_dim=cfg.ffn_dim,
+                          num_layers=2, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim)
+    sd = O.make_weights(ocfg, seed=0)
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, 16, 4, 64, 64, generator=g)
+    text = torch.randn(1, 512, cfg.text_dim, generator=g) * 0.1
+    t = torch.tensor([900])
+    with torch.no_grad():
+        O.dit_forward(sd, ocfg, lat[:, :, :1], t, text)  # warm the thread pool on a small clip
+        t0 = time.perf_counter()
+        O.dit_forward(sd, ocfg, lat, t, text)
+        dt = time.perf_counter() - t0
+    per_block = dt / 2
+    scene_s = per_block * cfg.num_layers * 100
+    return dict(value=1.0 / scene_s, unit="scenes/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle WanDiT fp32, N=4096 B=1, 2 of {cfg.num_layers} blocks in {dt:.2f}s; scene = {cfg.num_layers} blocks x 100 forwards "
+                       f"(extrapolated, {scene_s:.0f}s/scene); VAE decode + reconstruction (5% of FLOPs) not included")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--num-frames", type=int, default=13)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from vist3a_amd import ops
+    from vist3a_amd import lib
+    from vist3a_amd.t23d import SceneTimes, Text23DGS, synthetic_text_embeddings
+    from vist3a_amd.wan.dit import WAN_1_3B
+    lib.load()
+    cfg = WAN_1_3B
+    model = Text23DGS.synthetic(cfg, seed=0, device=dev)
+    pe, ne = synthetic_text_embeddings(dev)
+    Tl = (a.num_frames - 1) // 4 + 1
+    N = Tl * 32 * 32
+
+    def scene(i, timings=None):
+        # the reference seeds once per process and strides prompts over ranks: scene i of this rank = global prompt i*world+rank
+        g = torch.Generator().manual_seed(12413 + i * world + rank)
+        lat0 = torch.randn(1, 16, Tl, 64, 64, generator=g)
+        out, _, _ = model.generate(pe, ne, latents=lat0, num_frames=a.num_frames, num_inference_steps=a.denoise_steps,
+                                   guidance_scale=7.5, timings=timings)
+        return out
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        scene(-1 - i)
+    # dominant kernel = the bf16 GEMM tile every N=1536/3072/8960-wide projection resolves to (one kernel symbol)
+    dom_tile = lib.load().v3a_gemm_pick_tile(2 * N, cfg.dim)
+    probe = ops.GemmProbe(dom_tile)
+    ops.set_gemm_probe(probe)
+    stage = SceneTimes()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(a.steps):
+        last = i == a.steps - 1
+        probe.active = last  # HIP-event pairs around every launch of the dominant kernel during the last timed scene
+        out = scene(i, stage if last else None)
+    sync()
+    dt = time.perf_counter() - t0
+    probe.active = False
+    ops.set_gemm_probe(None)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    if rank == 0:
+        ps = probe.summary()
+        ach = ps["flops_per_launch"] / (ps["avg_ms"] * 1e-3) / 1e12 if ps["launches"] else 0.0
+        fwd_flops = dit_flops_per_forward(N, cfg.dim, cfg.ffn_dim, cfg.num_layers)
+        U = int(out.gaussians.means.shape[1])
+        line = {
+            "metric": "3D Gaussian scenes/sec (50-step denoise, 512^2, 13 views)",
+            "value": world * a.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (seeded random weights of production shapes, synthetic text embeddings)",
+            "config": {"workload": f"Wan-1.3B stitched, {a.denoise_steps}-step CFG denoise (batch-2 cond/uncond), {a.num_frames} views @512, "
+                                   "VAE decode, 448^2 AnySplat enc_blocks_2 reconstruction with voxel fusion; 1 prompt per GPU (data parallel)",
+                       "denoise_steps": a.denoise_steps, "views": a.num_frames, "dit_tokens": N, "gaussians_last_scene": U,
+                       "stage_ms_last_scene": {"denoise": round(stage.denoise_ms, 1), "vae_decode+resize": round(stage.vae_ms, 1),
+                                               "stitch+recon": round(stage.recon_ms, 1)},
+                       "dit_model_tflops_per_s": round(2 * a.denoise_steps * fwd_flops / (stage.denoise_ms * 1e-3) / 1e12, 1)},
+            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<{lib.load().v3a_gemm_tile_name(dom_tile).decode()}> (bf16 MFMA 32x32x16)",
+                         "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "launches_timed": ps["launches"], "avg_launch_ms": round(ps["avg_ms"], 4),
+                         "flops_per_launch": ps["flops_per_launch"]},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

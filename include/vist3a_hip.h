@@ -71,6 +71,7 @@ typedef struct {
 } v3a_gemm_args;
 int v3a_gemm_bf16_nt(const v3a_gemm_args* args, void* stream);
 int v3a_gemm_num_tiles(void);
+int v3a_gemm_pick_tile(int M, int N);   /* the tile index tile=-1 resolves to (profiling / roofline bookkeeping) */
 const char* v3a_gemm_tile_name(int tile);
 
 /* ------------------------------------------------------------------------------------------------

@@ -372,6 +372,7 @@ int launch(const GemmP& p, int ti, bool conv, void* stream) {
 }  // namespace
 
 extern "C" int v3a_gemm_num_tiles(void) { return kNumTiles; }
+extern "C" int v3a_gemm_pick_tile(int M, int N) { return (M > 0 && N > 0) ? pick_tile(M, N) : V3A_ERR_SHAPE; }
 extern "C" const char* v3a_gemm_tile_name(int t) { return (t >= 0 && t < kNumTiles) ? kTiles[t].name : ""; }
 
 extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {

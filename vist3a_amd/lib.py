@@ -100,6 +100,7 @@ SYMBOLS = {
     "v3a_build_info": (C.c_char_p, []),
     "v3a_gemm_bf16_nt": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "v3a_gemm_num_tiles": (C.c_int, []),
+    "v3a_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
     "v3a_gemm_tile_name": (C.c_char_p, [C.c_int]),
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),

@@ -1,0 +1,111 @@
+"""`AnySplatStitched` — drop-in for /root/reference/models/anysplat_stitched.py:143-525 on the inference path.
+
+forward(context_latent[b, C, v, hp, wp], context_image[B, 3, S, H, W] in [-1,1], train) -> EncoderOutput
+(train=True additionally returns anchor_feats [B,S,83,H,W], conf [B,S,H,W], depth_conf [B,S,H,W], :501-514).
+The arithmetic runs in vist3a_amd.recon.engine.ReconEngine (HIP kernels); this class owns the reference's attribute
+surface that callers touch: `.encoder.aggregator.patch_embed.{cls_token, register_tokens, mask_token}` (assigned by the
+checkpoint loader, nvs_eval.py:53-61), `.encoder.cfg.voxelize` (model_stitching_training.py:331), `.decoder` (rasteriser,
+out of scope: SURVEY.md §8f rank 1)."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+
+from ..recon.engine import ReconCfg, ReconEngine
+from .types import EncoderOutput, Gaussians
+
+
+class AnySplatWeights:
+    """What the reference calls `feedforward_model` (an `AnySplat` instance): here just its tensors + hyper-parameters."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: Optional[ReconCfg] = None, n_total_dino_blocks: Optional[int] = None):
+        self.state_dict, self.cfg = state_dict, cfg or ReconCfg()
+        self.n_total_dino_blocks = n_total_dino_blocks
+
+
+class AnySplatStitched(torch.nn.Module):
+    def __init__(self, model: AnySplatWeights, stitching_layer: str, device="cuda"):
+        super().__init__()
+        self.stitching_layer = stitching_layer
+        self.stitched_layer_index = int(stitching_layer.split("_")[-1])  # "enc_blocks_k": DINO patch-embed + first k blocks dropped
+        sd, cfg = dict(model.state_dict), model.cfg
+        pe = "encoder.aggregator.patch_embed.blocks."
+        present = sorted({int(k[len(pe):].split(".")[0]) for k in sd if k.startswith(pe)})
+        if model.n_total_dino_blocks is not None and len(present) == model.n_total_dino_blocks:
+            # full upstream checkpoint: delete the first k blocks and re-index, as convert_model_to_stitched_model (:158-165)
+            k = self.stitched_layer_index
+            for key in [q for q in sd if q.startswith(pe)]:
+                i = int(key[len(pe):].split(".")[0])
+                v = sd.pop(key)
+                if i >= k:
+                    sd[pe + str(i - k) + key[len(pe) + len(str(i)):]] = v
+            present = present[k:]
+        if len(present) != cfg.n_dino:
+            raise ValueError(f"state dict holds {len(present)} DINO blocks after stitching, config expects {cfg.n_dino}")
+        self._sd, self._cfg, self._device = sd, cfg, torch.device(device)
+        self._engine: Optional[ReconEngine] = None
+        P = torch.nn.Parameter
+        a = "encoder.aggregator.patch_embed."
+        patch_embed = torch.nn.Module()
+        patch_embed.cls_token = P(sd[a + "cls_token"].clone(), requires_grad=False)
+        patch_embed.register_tokens = P(sd[a + "register_tokens"].clone(), requires_grad=False)
+        patch_embed.mask_token = P(sd.get(a + "mask_token", torch.zeros(1, cfg.C)).clone(), requires_grad=False)
+        aggregator = torch.nn.Module()
+        aggregator.patch_embed = patch_embed
+        self.encoder = torch.nn.Module()
+        self.encoder.aggregator = aggregator
+        self.encoder.cfg = SimpleNamespace(voxelize=cfg.voxelize, voxel_size=cfg.voxel_size, pred_head_type="depth", render_conf=False,
+                                           opacity_conf=False, conf_threshold=0.1)
+        self.encoder.raw_gs_dim = 1 + 7 + 3 * (cfg.sh_degree + 1) ** 2
+        self.decoder = None
+        self.grad_checkpointing = False
+
+    def load_lora(self, lora_sd: Dict[str, torch.Tensor], alpha: float, r: int) -> int:
+        from ..recon.weights import merge_lora
+        self._engine = None
+        return merge_lora(self._sd, lora_sd, alpha, r)
+
+    def engine(self) -> ReconEngine:
+        pe = self.encoder.aggregator.patch_embed
+        a = "encoder.aggregator.patch_embed."
+        dirty = self._engine is None or self._cfg.voxelize != self.encoder.cfg.voxelize
+        for name in ("cls_token", "register_tokens"):
+            if not torch.equal(getattr(pe, name).detach().cpu().float(), self._sd[a + name].detach().cpu().float()):
+                self._sd[a + name] = getattr(pe, name).detach().clone()
+                dirty = True
+        if dirty:
+            self._cfg.voxelize = bool(self.encoder.cfg.voxelize)
+            self._engine = ReconEngine(self._cfg, self._sd, self._device)
+        return self._engine
+
+    def package(self, out: dict, S: int, H: int, W: int, train: bool):
+        """raw engine outputs -> EncoderOutput exactly as anysplat_stitched.py:448-525 assembles it (batch dim b = 1)."""
+        g = out["gaussians"]
+        gauss = Gaussians(**{k: v[None] for k, v in g.items()})
+        ext, K = out["extrinsic_w2c"][None], out["intrinsic_px"][None]
+        pad = torch.tensor([0, 0, 0, 1.0], device=ext.device, dtype=ext.dtype).view(1, 1, 1, 4).repeat(1, S, 1, 1)
+        Kn = torch.stack([K[:, :, 0] / W, K[:, :, 1] / H, K[:, :, 2]], 2)
+        pose = dict(extrinsic=torch.cat([ext, pad], 2).inverse(), intrinsic=Kn)
+        depth = out["depth"].view(1, S, H, W, 1)
+        dconf = out["depth_conf"].view(1, S, H, W)
+        U = g["means"].shape[0]
+        poses = [p[None] for p in out["pred_pose_enc_list"]]
+        eo = EncoderOutput(gaussians=gauss, pred_pose_enc_list=poses, pred_context_pose=pose,
+                           depth_dict=dict(depth=depth, conf_valid_mask=torch.ones_like(dconf, dtype=torch.bool)),
+                           infos=dict(scene_scale=out["scene_scale"], voxelize_ratio=U / (H * W * S)), distill_infos=None,
+                           last_pred_pose_enc=None if train else poses[-1])
+        if not train:
+            return eo
+        gsd = self.encoder.raw_gs_dim
+        raw = out["raw_gs"].view(1, S, H, W, -1).permute(0, 1, 4, 2, 3)
+        return eo, raw[:, :, :gsd], raw[:, :, gsd], dconf
+
+    @torch.no_grad()
+    def forward(self, context_latent: torch.Tensor, context_image: torch.Tensor, train: bool = False):
+        B, c, S, H, W = context_image.shape
+        if B != 1 or context_latent.shape[0] != 1:
+            raise NotImplementedError("batch size 1 (the reference's inference path decodes one scene at a time)")
+        out = self.engine().forward(context_latent, context_image)
+        return self.package(out, S, H, W, train)

@@ -1,0 +1,88 @@
+"""`StitchVAE3D` — drop-in for /root/reference/models/stitched_model.py:12-182 on the inference path.
+
+Same constructor signature and attributes (`.device`, `.diffusion_vae`, `.stitching_layer`, `.stitched_3d_model`,
+`.pre_upsample_layer`, `.vae_latent_dimension`, `.feedforward_dimension`); `forward_with_latent(latent, feedforward_image,
+train=False)` is the entry /root/reference/inference_t23d.py:133-137 calls.  On MI355X the three stages the reference chains
+through NCTHW tensors (trilinear T-upsample -> Conv3d -> token rearrange) collapse into: one lerp kernel that emits the
+channels-last bf16 clip, and one implicit-GEMM conv whose epilogue adds the positional embedding and scatters rows
+straight into the reconstruction engine's token buffer."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import ops
+from .anysplat_stitched import AnySplatStitched, AnySplatWeights
+from .stitching_layer_builder import ConvSpec, StitchingConv
+
+
+class StitchVAE3D(torch.nn.Module):
+    def __init__(self, diffusion_vae, feedforward_model, device, stitching_layer_location: str, stitching_layer_config: ConvSpec,
+                 resolution: int, stitching_layer_init_path: Optional[str] = None):
+        super().__init__()
+        self.device = torch.device(device)
+        self.diffusion_vae = diffusion_vae
+        # WAN VAE: C=16 latents, 8x spatial stride; T is nominal (stitched_model.py:49-64: only H, W are used)
+        self.vae_latent_dimension = torch.tensor([13, 16, resolution // 8, resolution // 8])
+        if not isinstance(feedforward_model, AnySplatWeights):
+            raise NotImplementedError(f"Feedforward model preprocessing not implemented for {type(feedforward_model)}")
+        self.stitched_3d_model = AnySplatStitched(feedforward_model, stitching_layer_location, device=self.device)
+        self.feedforward_dimension = torch.tensor([13, feedforward_model.cfg.C, 448, 448])
+        if not isinstance(stitching_layer_config, ConvSpec):
+            raise TypeError("stitching_layer_config must be a ConvSpec (parse_conv_spec)")
+        self.stitching_layer: StitchingConv = stitching_layer_config.build(in_channels=int(self.vae_latent_dimension[1]))
+        if stitching_layer_init_path is not None:
+            sd = torch.load(stitching_layer_init_path, map_location="cpu", weights_only=False)
+            sd = sd.get("state_dict", sd)
+            self.stitching_layer.load_state_dict(sd, strict=True)
+        self._packed = None
+        self._packed_key = None
+
+    def pre_upsample_layer(self, x: torch.Tensor) -> torch.Tensor:
+        """[1,16,Tl,h,w] -> [1,16,4(Tl-1)+1,h,w]: trilinear align_corners=True, H/W unchanged (stitched_model.py:92-107)."""
+        cl = ops.latent_upsample_t_cl(x[0].to(device=self.device, dtype=torch.float32).contiguous())
+        return cl.permute(3, 0, 1, 2).unsqueeze(0).float()
+
+    def _conv_weight(self) -> ops.ConvWeight:
+        w, b = self.stitching_layer.weight, self.stitching_layer.bias
+        key = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()))
+        if self._packed is None or key != self._packed_key:
+            wd = w.detach()
+            wd = wd.reshape(wd.shape[0], wd.shape[1], *((1,) * (5 - wd.dim())), *wd.shape[2:]) if wd.dim() < 5 else wd
+            self._packed, self._packed_key = ops.ConvWeight(wd, None if b is None else b.detach(), device=self.device), key
+        return self._packed
+
+    def forward(self, images, feedforward_image, train=False):
+        raise NotImplementedError("the image-conditioned path needs the Wan VAE *encoder* (SURVEY.md §8f rank 4: next row); "
+                                  "text->3DGS inference enters through forward_with_latent")
+
+    @torch.no_grad()
+    def forward_with_latent(self, latent: torch.Tensor, feedforward_image: torch.Tensor, train: bool = False, image_cl: Optional[torch.Tensor] = None):
+        """latent: de-normalised VAE latent [1,16,Tl,64,64]; feedforward_image [1,3,T,448,448] in [-1,1]
+        (or, MI355X fast path, image_cl [T,448,448,8] bf16 in [-1,1] as produced by WanVAEDecoder.decode_cl + resize)."""
+        if latent.shape[0] != 1:
+            raise NotImplementedError("batch size 1")
+        st = self.stitching_layer
+        model = self.stitched_3d_model
+        eng = model.engine()
+        lat_cl = ops.latent_upsample_t_cl(latent[0].to(device=self.device, dtype=torch.float32).contiguous())
+        S = lat_cl.shape[0]
+        if image_cl is None:
+            H, W = feedforward_image.shape[-2:]
+            image_cl = torch.zeros(S, H, W, 8, device=self.device, dtype=torch.bfloat16)
+            image_cl[..., :3] = feedforward_image[0].to(self.device).permute(1, 2, 3, 0)
+        else:
+            H, W = image_cl.shape[1:3]
+        img01 = (image_cl + 1) / 2  # context_image = (context_image + 1) / 2  (anysplat_stitched.py:175)
+        img01[..., 3:] = 0
+        x, g = eng.token_workspace(S, H, W)
+        hw, Pp, nsp = g["hw"], g["Pp"], g["nsp"]
+        cw = self._conv_weight()
+        oshape = [(lat_cl.shape[i] + 2 * st.padding3[i] - st.kernel3[i]) // st.stride3[i] + 1 for i in range(3)]
+        if oshape[0] != S or oshape[1] * oshape[2] != hw or cw.CoutP != eng.cfg.C:
+            raise ValueError(f"stitching layer output {oshape}x{cw.Cout} does not match the {S}x{g['hp']}x{g['wp']}x{eng.cfg.C} token grid")
+        ops.conv(lat_cl, cw, out=x, stride=st.stride3, pad=st.padding3, out_size=tuple(oshape), replicate=True,
+                 residual=g["pos_patch"], res_row_mod=hw, out_rows=(hw, Pp - hw, nsp))
+        out = eng.forward_tokens_filled(S, H, W, img01.contiguous())
+        return model.package(out, S, H, W, train)

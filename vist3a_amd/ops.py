@@ -32,6 +32,29 @@ def _chk2d(t: torch.Tensor, name: str, dtypes) -> None:
         raise ValueError(f"{name} must be 2-D with a contiguous last dim, got shape {tuple(t.shape)} stride {t.stride()}")
 
 
+class GemmProbe:
+    """Optional HIP-event instrumentation of the GEMM launches that resolve to one tile configuration (= one kernel symbol):
+    accumulates algorithmic FLOPs and event pairs so bench.py can report that kernel's live roofline numbers."""
+
+    def __init__(self, tile: int):
+        self.tile, self.flops, self.events, self.active = tile, 0.0, [], False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        n = len(ms)
+        return dict(launches=n, total_ms=sum(ms), avg_ms=(sum(ms) / n if n else 0.0), flops=self.flops,
+                    flops_per_launch=(self.flops / n if n else 0.0))
+
+
+_probe: Optional[GemmProbe] = None
+
+
+def set_gemm_probe(p: Optional[GemmProbe]) -> None:
+    global _probe
+    _probe = p
+
+
 def gemm(
     a: torch.Tensor,
     w: torch.Tensor,
@@ -100,6 +123,15 @@ def gemm(
         _ptr(residual2), residual2.stride(0) if residual2 is not None else 0, res_row_mod,
         *(out_rows if out_rows is not None else (0, 0, 0)),
     )
+    pr = _probe
+    if pr is not None and pr.active and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile(M, N)) == pr.tile:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")
+        e1.record()
+        pr.events.append((e0, e1))
+        pr.flops += 2.0 * M * N * K
+        return out
     L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")
     return out
 

@@ -154,10 +154,11 @@ class ReconEngine:
         dev, a = self.dev, "encoder.aggregator."
         pe = a + "patch_embed."
         Fv = lambda k: sd[k].to(device=dev, dtype=f32).contiguous()
-        self.cls_token, self.register_tokens, self.pos_embed = sd[pe + "cls_token"], sd[pe + "register_tokens"], sd[pe + "pos_embed"]
+        cpu = lambda k: sd[k].detach().float().cpu()
+        self.cls_token, self.register_tokens, self.pos_embed = cpu(pe + "cls_token"), cpu(pe + "register_tokens"), cpu(pe + "pos_embed")
         self.dino = [_Block(sd, pe + f"blocks.{i}.", dev, False) for i in range(cfg.n_dino)]
         self.dino_nw, self.dino_nb = Fv(pe + "norm.weight"), Fv(pe + "norm.bias")
-        self.camera_token, self.register_token = sd[a + "camera_token"], sd[a + "register_token"]
+        self.camera_token, self.register_token = cpu(a + "camera_token"), cpu(a + "register_token")
         self.frame = [_Block(sd, a + f"frame_blocks.{i}.", dev, True) for i in range(cfg.depth)]
         self.glob = [_Block(sd, a + f"global_blocks.{i}.", dev, True) for i in range(cfg.depth)]
         c = "encoder.camera_head."

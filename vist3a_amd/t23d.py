@@ -1,0 +1,141 @@
+"""Text -> 3D-Gaussian-splat scene: the per-prompt body of /root/reference/inference_t23d.py:85-137 as one object.
+
+    latents  = WanPipeline(..., output_type="latent")          50-step CFG denoise (DiT + UniPC)          :94-103
+    latents  = latents * std + mean                              de-normalise                              :105-113
+    samples  = vae.decode(latents)                               13 x 512^2 RGB                            :114
+    feedfwd  = trilinear(samples -> (T, 448, 448), align=False)                                            :118-123
+    output   = stitched_decoder.forward_with_latent(latents, feedfwd, train=False)                         :131-137
+
+Everything stays on the device and, between the VAE decoder and the reconstruction heads, in channels-last bf16."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import ops
+from .models.anysplat_stitched import AnySplatWeights
+from .models.stitched_model import StitchVAE3D
+from .models.stitching_layer_builder import parse_conv_spec
+from .models.types import EncoderOutput
+from .recon.engine import ReconCfg
+from .recon.weights import random_recon_state_dict, round_aggregator_to_bf16
+from .wan.dit import WAN_1_3B, WanDiT, WanDiTConfig
+from .wan.pipeline import WanT2VPipeline, denormalize_latents
+from .wan.scheduler import UniPCMultistepScheduler
+from .wan.vae import WanVAEConfig, WanVAEDecoder
+from .wan.weights import random_dit_state_dict
+
+
+@dataclass
+class SceneTimes:
+    denoise_ms: float = 0.0
+    vae_ms: float = 0.0
+    recon_ms: float = 0.0
+
+
+class Text23DGS:
+    def __init__(self, transformer: WanDiT, vae: WanVAEDecoder, stitched_decoder: StitchVAE3D, flow_shift: float = 5.0,
+                 feedforward_resolution: int = 448, device="cuda"):
+        self.device = torch.device(device)
+        self.transformer, self.vae, self.stitched_decoder = transformer, vae, stitched_decoder
+        self.pipe = WanT2VPipeline(transformer, UniPCMultistepScheduler(flow_shift=flow_shift), vae=vae, device=device)
+        self.ff_res = feedforward_resolution
+
+    @classmethod
+    def synthetic(cls, dit_cfg: WanDiTConfig = WAN_1_3B, seed: int = 0, device="cuda", flow_shift: float = 5.0,
+                  stitch_spec: str = "conv3d_k5x3x3_o1024_s1x2x2_p2x1x1", stitch_location: str = "enc_blocks_2",
+                  recon_cfg: Optional[ReconCfg] = None, vae_cfg: Optional[WanVAEConfig] = None, resolution: int = 512):
+        """Seeded random weights of the exact production shapes (no checkpoint is reachable offline)."""
+        dit = WanDiT(dit_cfg, random_dit_state_dict(dit_cfg, seed=seed, device=device), device=device)
+        vcfg = vae_cfg or WanVAEConfig()
+        vae = WanVAEDecoder(vcfg, random_vae_decoder_state_dict(vcfg, seed + 1, device), device=device)
+        rcfg = recon_cfg or ReconCfg()
+        rsd = round_aggregator_to_bf16(random_recon_state_dict(rcfg, seed=seed + 2, device=device))
+        dec = StitchVAE3D(vae, AnySplatWeights(rsd, rcfg), device, stitch_location, parse_conv_spec(stitch_spec), resolution)
+        g = torch.Generator().manual_seed(seed + 3)
+        with torch.no_grad():
+            dec.stitching_layer.weight.copy_(torch.randn(dec.stitching_layer.weight.shape, generator=g) * 0.02)
+            dec.stitching_layer.bias.copy_(torch.randn(dec.stitching_layer.bias.shape, generator=g) * 0.02)
+        return cls(dit, vae, dec, flow_shift=flow_shift, device=device)
+
+    @torch.no_grad()
+    def generate(self, prompt_embeds: torch.Tensor, negative_prompt_embeds: torch.Tensor, *, latents: Optional[torch.Tensor] = None,
+                 generator: Optional[torch.Generator] = None, num_frames: int = 13, num_inference_steps: int = 50,
+                 guidance_scale: float = 7.5, height: int = 512, width: int = 512, timings: Optional[SceneTimes] = None):
+        """-> (EncoderOutput, de-normalised latents, channels-last decoded clip [T,512,512,8] in [-1,1])"""
+        ev = (lambda: _event()) if timings is not None else (lambda: None)
+        e0 = ev()
+        lat = self.pipe(prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, height=height, width=width,
+                        num_frames=num_frames, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                        latents=latents, generator=generator, output_type="latent")["frames"]
+        lat = denormalize_latents(lat)
+        e1 = ev()
+        clip_cl = self.vae.decode_cl(lat)
+        ff_cl = ops.bilinear_cl(clip_cl, (self.ff_res, self.ff_res), align_corners=False)
+        e2 = ev()
+        out = self.stitched_decoder.forward_with_latent(lat, None, train=False, image_cl=ff_cl)
+        e3 = ev()
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings.denoise_ms, timings.vae_ms, timings.recon_ms = e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)
+        return out, lat, clip_cl
+
+
+def _event():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def random_vae_decoder_state_dict(cfg: WanVAEConfig, seed: int = 0, device="cpu"):
+    """Seeded Wan-VAE decoder (+post_quant_conv) weights under the reference's names (utils/wan_utils.py:745-1000)."""
+    import math
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+
+    def conv(name, o, i, k):
+        sd[name + ".weight"] = torch.randn(o, i, *k, generator=g, device=device) / math.sqrt(i * math.prod(k))
+        sd[name + ".bias"] = torch.randn(o, generator=g, device=device) * 0.02
+
+    def gamma(name, c, nd):
+        sd[name + ".gamma"] = 1 + 0.05 * torch.randn(c, *([1] * nd), generator=g, device=device)
+
+    def res(p, i, o):
+        gamma(p + "norm1", i, 3); conv(p + "conv1", o, i, (3, 3, 3)); gamma(p + "norm2", o, 3); conv(p + "conv2", o, o, (3, 3, 3))
+        if i != o:
+            conv(p + "conv_shortcut", o, i, (1, 1, 1))
+
+    conv("post_quant_conv", cfg.z_dim, cfg.z_dim, (1, 1, 1))
+    d0, plan = cfg.decoder_plan()
+    d = "decoder."
+    conv(d + "conv_in", d0, cfg.z_dim, (3, 3, 3))
+    res(d + "mid_block.resnets.0.", d0, d0)
+    gamma(d + "mid_block.attentions.0.norm", d0, 2)
+    conv(d + "mid_block.attentions.0.to_qkv", 3 * d0, d0, (1, 1))
+    conv(d + "mid_block.attentions.0.proj", d0, d0, (1, 1))
+    res(d + "mid_block.resnets.1.", d0, d0)
+    for i, (i_d, o_d, mode) in enumerate(plan):
+        cur = i_d
+        for j in range(cfg.num_res_blocks + 1):
+            res(d + f"up_blocks.{i}.resnets.{j}.", cur, o_d)
+            cur = o_d
+        if mode is not None:
+            conv(d + f"up_blocks.{i}.upsamplers.0.resample.1", o_d // 2, o_d, (3, 3))
+            if mode == "upsample3d":
+                conv(d + f"up_blocks.{i}.upsamplers.0.time_conv", 2 * o_d, o_d, (3, 1, 1))
+    gamma(d + "norm_out", plan[-1][1], 3)
+    conv(d + "conv_out", 3, plan[-1][1], (3, 3, 3))
+    sd[d + "conv_out.weight"] *= 0.25
+    return sd
+
+
+def synthetic_text_embeddings(device="cuda", seed: int = 12413, L_pos: int = 64, L_neg: int = 80, max_len: int = 512, dim: int = 4096):
+    """randn*0.1 rows for the first L tokens, zero rows after (the pipeline zero-pads to 512, no mask)."""
+    g = torch.Generator().manual_seed(seed)
+    pe = torch.zeros(1, max_len, dim)
+    ne = torch.zeros(1, max_len, dim)
+    pe[:, :L_pos] = torch.randn(1, L_pos, dim, generator=g) * 0.1
+    ne[:, :L_neg] = torch.randn(1, L_neg, dim, generator=g) * 0.1
+    return pe.to(device), ne.to(device)

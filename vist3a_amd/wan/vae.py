@@ -122,6 +122,15 @@ class WanVAEDecoder:
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):
+        """AutoencoderKLWan.decode surface: [1,16,T_lat,h,w] -> ([1,3,T,8h,8w] bf16 in [-1,1],)"""
+        y = self.decode_cl(z)
+        video = y[..., :3].permute(3, 0, 1, 2).unsqueeze(0).contiguous()
+        return video if return_dict else (video,)
+
+    @torch.no_grad()
+    def decode_cl(self, z: torch.Tensor) -> torch.Tensor:
+        """Same decode, result left channels-last [T, 8h, 8w, 8] bf16 (RGB in channels 0-2, clamped to [-1,1]) — the layout
+        the resize kernel and the reconstruction heads consume, so the decoded clip never takes an NCHW round trip."""
         if z.dim() != 5 or z.shape[0] != 1:
             raise ValueError("expected z [1, z_dim, T, h, w]")
         x = z[0].permute(1, 2, 3, 0).to(device=self.device, dtype=bf16).contiguous()  # [T,h,w,16]
@@ -145,6 +154,5 @@ class WanVAEDecoder:
                 x = y
             x = ops.conv(x, rs, pad=(0, 1, 1), ups2=True)
         n = ops.rownorm_act(x, self.g_out, mode=1, act=L.ACT_SILU)
-        y = ops.conv(n, self.conv_out, pad=(2, 1, 1))  # [T,H,W,8] (3 real channels)
-        video = y[..., :3].permute(3, 0, 1, 2).unsqueeze(0).clamp(-1.0, 1.0).contiguous()
-        return video if return_dict else (video,)
+        y = ops.conv(n, self.conv_out, pad=(2, 1, 1))  # [T,H,W,8] (3 real channels, 5 zero)
+        return y.clamp_(-1.0, 1.0)
