@@ -1,0 +1,79 @@
+"""Text -> 3DGS inference CLI — drop-in for /root/reference/inference_t23d.py (same flags, same output layout
+`<output_dir>/<prompt[:100] sans '/'>/{prompt.txt, gaussians.ply}`; gs.mp4 / depth.mp4 need the rasteriser: SURVEY.md §8f rank 1).
+
+    python -m torch.distributed.run --nproc_per_node=K --master-addr 127.0.0.1 inference_t23d.py --checkpoint_path ... \
+        --transformer_lora_path ... --input_texts_path prompts.txt
+
+One process per GPU; prompts are strided over ranks (no inter-GPU traffic), exactly like the reference (:53-62)."""
+from __future__ import annotations
+
+import os
+import sys
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+from vist3a_amd.models.loading import load_stitching_model  # noqa: E402
+from vist3a_amd.t23d import Text23DGS, synthetic_text_embeddings  # noqa: E402
+from vist3a_amd.utils.argument import inference_vist3a_argument  # noqa: E402
+from vist3a_amd.utils.dist_util import setup_dist, shard_prompts  # noqa: E402
+from vist3a_amd.utils.ply_export import export_ply  # noqa: E402
+from vist3a_amd.wan.dit import WAN_1_3B, WAN_14B, WanDiT  # noqa: E402
+from vist3a_amd.wan.weights import load_dit_state_dict, load_peft_lora, random_dit_state_dict  # noqa: E402
+
+PROMPT_TEMPLATE = "The camera rotates around the scene, maintaining constant distance: `{}`. The orbiting trajectory captures 3D structure and consistency."
+NEGATIVE_PROMPT = ("Background blur, Blurred background, Blurred scene, Artifacts, not aesthetic, not realistic, rendered noise, low quality movement, "
+                   "low quality video, low quality image, deformed, disfigured, distorted, extra limbs, cloned face, skinny, glitchy, double torso, "
+                   "extra arms, extra hands, mangled fingers, missing lips, ugly face, distorted legs, fused fingers, too many fingers, long neck")
+
+
+def build_transformer(args, device):
+    cfg = WAN_14B if "14B" in args.model_id else WAN_1_3B
+    if args.checkpoint_path == "synthetic" and not os.path.isdir(args.model_id):
+        sd = random_dit_state_dict(cfg, seed=0, device=str(device))
+    else:
+        sd = load_dit_state_dict(args.model_id)
+    if args.transformer_lora_path not in ("none", "", None):
+        load_peft_lora(args.transformer_lora_path, sd)  # merged at load: W += (alpha/r) B A
+    return WanDiT(cfg, sd, device=device)
+
+
+def main(args):
+    setup_dist()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    device = torch.device(f"cuda:{rank % torch.cuda.device_count()}")
+    torch.cuda.set_device(device)
+    with open(args.input_texts_path, "r") as f:
+        prompts = shard_prompts([line.strip() for line in f.readlines()], rank, world)
+    gen = torch.Generator().manual_seed(12413)  # seed_everything(12413): one stream per process, consumed in prompt order
+    transformer = build_transformer(args, device)
+    stitched = load_stitching_model(args)
+    scene = Text23DGS(transformer, stitched.diffusion_vae, stitched, flow_shift=args.flow_shift,
+                      feedforward_resolution=args.feedforward_resolution, device=device)
+    embeds = torch.load(args.text_embeds_path, map_location="cpu") if args.text_embeds_path else None
+    for prompt in prompts:
+        if embeds is not None:
+            pe, ne = embeds[PROMPT_TEMPLATE.format(prompt)][None].to(device), embeds["__negative__"][None].to(device)
+        elif args.synthetic_text:
+            pe, ne = synthetic_text_embeddings(device, seed=abs(hash(prompt)) % (2 ** 31))
+        else:
+            raise RuntimeError("no text encoder on this path: pass --text_embeds_path (precomputed UMT5 embeddings) or --synthetic_text")
+        out, _, _ = scene.generate(pe, ne, generator=gen, num_frames=args.num_frames, num_inference_steps=args.num_inference_steps,
+                                   guidance_scale=float(args.cfg_scale), height=args.resolution, width=args.resolution)
+        save = Path(args.output_dir) / prompt[:100].replace("/", "")
+        os.makedirs(save, exist_ok=args.overwrite)  # the reference raises when the directory exists (inference_t23d.py:126)
+        (save / "prompt.txt").write_text(prompt)
+        g = out.gaussians
+        export_ply(g.means[0], g.scales[0], g.rotations[0], g.harmonics[0], g.opacities[0], save / "gaussians.ply", save_sh_dc_only=True)
+        print(f"[rank {rank}] {save}: {g.means.shape[1]} gaussians", flush=True)
+    if world > 1:
+        dist.barrier()
+
+
+if __name__ == "__main__":
+    main(inference_vist3a_argument().parse_args())

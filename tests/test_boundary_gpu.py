@@ -1,0 +1,84 @@
+"""GPU: the drop-in boundary objects (StitchVAE3D.forward_with_latent / AnySplatStitched.forward / Text23DGS.generate) against
+the oracle on seeded inputs, at reduced width, plus full-size size-independent properties."""
+import pytest
+import torch
+
+from oracle import recon as R
+
+pytestmark = pytest.mark.gpu
+RECON_TINY = dict(C=64, heads=1, n_dino=22, depth=24, cam_heads=2, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def test_forward_with_latent_matches_oracle(hip_lib):
+    from vist3a_amd.models.anysplat_stitched import AnySplatWeights
+    from vist3a_amd.models.stitched_model import StitchVAE3D
+    from vist3a_amd.models.stitching_layer_builder import parse_conv_spec
+    from vist3a_amd.models.types import EncoderOutput
+    from vist3a_amd.recon.engine import ReconCfg
+    ocfg = R.ReconCfg(**RECON_TINY)
+    sd = R.make_recon_weights(ocfg, seed=7)
+    model = StitchVAE3D(None, AnySplatWeights(dict(sd), ReconCfg(**RECON_TINY)), "cuda", "enc_blocks_2",
+                        parse_conv_spec("conv3d_k5x3x3_o64_s1x2x2_p2x1x1"), resolution=32)
+    g = torch.Generator().manual_seed(8)
+    w = torch.randn(64, 16, 5, 3, 3, generator=g) * 0.08
+    b = torch.randn(64, generator=g) * 0.1
+    model.stitching_layer.weight.data, model.stitching_layer.bias.data = w, b   # assigned the way nvs_eval.py:51-52 does
+    Tl, S, H = 2, 5, 28
+    lat = torch.randn(1, 16, Tl, 4, 4, generator=g)
+    img = torch.rand(1, 3, S, H, H, generator=g) * 2 - 1
+    out = model.forward_with_latent(lat.cuda(), img.cuda(), train=False)
+    assert isinstance(out, EncoderOutput) and out.last_pred_pose_enc.shape == (1, S, 9)
+    with torch.no_grad():
+        feat = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1))
+        ora = R.recon_forward(sd, ocfg, feat, img)
+    r_pose = _rel(out.last_pred_pose_enc, ora["pred_pose_enc_list"][-1])
+    r_depth = _rel(out.depth_dict["depth"], ora["depth"])
+    r_c2w = _rel(out.pred_context_pose["extrinsic"], ora["pred_context_pose"]["extrinsic"])
+    print(f"boundary: pose {r_pose:.2e} depth {r_depth:.2e} c2w {r_c2w:.2e} U {out.gaussians.means.shape[1]} vs {ora['gaussians']['means'].shape[1]}")
+    assert r_pose < 3e-2 and r_depth < 2e-2 and r_c2w < 3e-2
+    assert out.gaussians.means.shape[0] == 1 and out.gaussians.covariances.shape[-2:] == (3, 3) and out.gaussians.harmonics.shape[-2:] == (3, 25)
+    U, Uo = out.gaussians.means.shape[1], ora["gaussians"]["means"].shape[1]
+    assert abs(U - Uo) <= 0.08 * Uo
+    # train=True returns the 4-tuple of anysplat_stitched.py:501-514
+    eo, anchor, conf, dconf = model.forward_with_latent(lat.cuda(), img.cuda(), train=True)
+    assert anchor.shape == (1, S, 83, H, H) and conf.shape == (1, S, H, H) and dconf.shape == (1, S, H, H)
+    # pre_upsample_layer == trilinear align_corners=True
+    up = model.pre_upsample_layer(lat.cuda()).cpu()
+    assert torch.allclose(up, R.upsample_T(lat).to(torch.bfloat16).float(), atol=1e-6)
+    # voxelize switch (model_stitching_training.py:331) is honoured
+    model.stitched_3d_model.encoder.cfg.voxelize = False
+    out2 = model.forward_with_latent(lat.cuda(), img.cuda())
+    assert out2.gaussians.means.shape[1] == S * H * H
+
+
+def test_scene_pipeline_properties_reduced(hip_lib):
+    """Text23DGS.generate end to end at reduced DiT/recon width but production 512^2/448^2 geometry: determinism, finiteness,
+    size-independent invariants (unit quaternions, symmetric PSD covariances, opacity in (0,1), scale clamp, sorted voxel keys)."""
+    from vist3a_amd.recon.engine import ReconCfg
+    from vist3a_amd.t23d import Text23DGS
+    from vist3a_amd.wan.dit import WanDiTConfig
+    from vist3a_amd.wan.vae import WanVAEConfig
+    dit = WanDiTConfig(num_attention_heads=2, attention_head_dim=128, ffn_dim=512, num_layers=2, text_dim=256, freq_dim=64)
+    m = Text23DGS.synthetic(dit, seed=0, device="cuda", recon_cfg=ReconCfg(**RECON_TINY), vae_cfg=WanVAEConfig(base_dim=16),
+                            stitch_spec="conv3d_k5x3x3_o64_s1x2x2_p2x1x1")
+    g = torch.Generator().manual_seed(1)
+    pe = torch.randn(1, 64, 256, generator=g) * 0.1
+    ne = torch.randn(1, 64, 256, generator=g) * 0.1
+    lat0 = torch.randn(1, 16, 2, 64, 64, generator=g)
+    o1, lat, clip = m.generate(pe.cuda(), ne.cuda(), latents=lat0.clone(), num_frames=5, num_inference_steps=3, guidance_scale=7.5)
+    o2, _, _ = m.generate(pe.cuda(), ne.cuda(), latents=lat0.clone(), num_frames=5, num_inference_steps=3, guidance_scale=7.5)
+    gs = o1.gaussians
+    assert clip.shape == (5, 512, 512, 8) and clip.abs().max() <= 1.0
+    assert torch.equal(gs.means, o2.gaussians.means) and torch.equal(gs.harmonics, o2.gaussians.harmonics)
+    for t in (gs.means, gs.covariances, gs.harmonics, gs.opacities, gs.scales, gs.rotations):
+        assert torch.isfinite(t).all()
+    assert torch.allclose(gs.rotations.norm(dim=-1), torch.ones_like(gs.opacities), atol=1e-4)
+    assert (gs.opacities > 0).all() and (gs.opacities < 1).all() and (gs.scales > 0).all() and gs.scales.max() <= 0.3 + 1e-6
+    cov = gs.covariances[0]
+    assert torch.allclose(cov, cov.transpose(-1, -2), atol=1e-9) and (torch.linalg.eigvalsh(cov.double().cpu()) > -1e-9).all()
+    assert gs.means.shape[1] <= 5 * 448 * 448

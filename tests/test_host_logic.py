@@ -1,0 +1,98 @@
+"""Host-side logic that needs no GPU: conv-spec grammar, CLI flags, LoRA merge, ply writer, prompt sharding over a
+world_size-2 gloo process group (the only multi-GPU mechanism the reference's inference path has: data parallel prompts)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_conv_spec_grammar():
+    from vist3a_amd.models.stitching_layer_builder import ConvSpec, parse_conv_spec
+    s = parse_conv_spec("conv3d_k5x3x3_o1024_s1x2x2_p2x1x1")
+    assert s == ConvSpec(dim=3, out_channels=1024, kernel_size=(5, 3, 3), stride=(1, 2, 2), padding=(2, 1, 1), dilation=1)
+    assert parse_conv_spec("conv2d_k3_o64") == ConvSpec(2, 64, 3, 1, 0, 1)
+    assert parse_conv_spec("CONV3D_k3x3x3_o32_s2_p1").stride == 2
+    for bad in ("conv4d_k3_o1", "conv3d_o3", "conv3d_k3x3x3", "foo"):
+        with pytest.raises(ValueError):
+            parse_conv_spec(bad)
+    layer = s.build(in_channels=16)
+    assert tuple(layer.weight.shape) == (1024, 16, 5, 3, 3) and layer.padding_mode == "replicate"
+
+
+def test_cli_flags_match_reference_surface():
+    from vist3a_amd.utils.argument import inference_vist3a_argument, parse_lora_mode
+    a = inference_vist3a_argument().parse_args(["--checkpoint_path", "c", "--transformer_lora_path", "l", "--input_texts_path", "t"])
+    assert (a.model_id, a.num_frames, a.flow_shift, a.cfg_scale, a.resolution, a.feedforward_resolution) == \
+        ("Wan-AI/Wan2.1-T2V-1.3B-Diffusers", 13, 5, "7.5", 512, 448)
+    assert a.stitching_layer_location == "enc_blocks_2" and a.lora_config == "r8,a16,d0.05,f0"
+    assert a.feedforward_model == "anysplat" and a.video_model == "wan" and a.output_dir == "inference_vist3a_results"
+    assert parse_lora_mode("r64,a32,d0.0,f0") == (64, 32)
+    with pytest.raises(SystemExit):
+        inference_vist3a_argument().parse_args([])
+
+
+def test_lora_merge_is_the_unmerged_map():
+    from vist3a_amd.wan.dit import merge_lora_into_state_dict
+    torch.manual_seed(0)
+    W, A, B = torch.randn(6, 5), torch.randn(2, 5), torch.randn(6, 2)
+    sd = {"blocks.0.attn1.to_q.weight": W.clone()}
+    n = merge_lora_into_state_dict(sd, {"base_model.model.blocks.0.attn1.to_q.lora_A.weight": A,
+                                        "base_model.model.blocks.0.attn1.to_q.lora_B.weight": B}, alpha=16, r=2)
+    x = torch.randn(3, 5)
+    assert n == 1 and torch.allclose(x @ sd["blocks.0.attn1.to_q.weight"].t(), x @ W.t() + 8.0 * (x @ A.t()) @ B.t(), atol=1e-5)
+
+
+def test_ply_roundtrip(tmp_path):
+    from vist3a_amd.utils.ply_export import export_ply
+    U = 7
+    g = torch.Generator().manual_seed(1)
+    q = torch.randn(U, 4, generator=g)
+    q = q / q.norm(dim=-1, keepdim=True)
+    means, scales, sh, op = torch.randn(U, 3, generator=g), torch.rand(U, 3, generator=g) + 0.1, torch.randn(U, 3, 25, generator=g), torch.rand(U, generator=g)
+    p = tmp_path / "g.ply"
+    export_ply(means, scales, q, sh, op, p)
+    raw = p.read_bytes()
+    head, body = raw.split(b"end_header\n")
+    assert b"element vertex 7" in head and head.count(b"property float") == 17 and b"binary_little_endian" in head
+    arr = np.frombuffer(body, dtype="<f4").reshape(U, 17)
+    assert np.allclose(arr[:, :3], means.numpy()) and np.allclose(arr[:, 6:9], sh[..., 0].numpy()) and np.allclose(arr[:, 9], op.numpy())
+    assert np.allclose(arr[:, 10:13], scales.log().numpy(), atol=1e-6)
+    wxyz = arr[:, 13:]
+    same = np.allclose(wxyz, q[:, [3, 0, 1, 2]].numpy(), atol=1e-5) or np.allclose(np.abs(wxyz), np.abs(q[:, [3, 0, 1, 2]].numpy()), atol=1e-5)
+    assert same
+
+
+_WORKER = '''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from vist3a_amd.utils.dist_util import setup_dist, shard_prompts, is_main_process
+setup_dist("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+mine = shard_prompts([f"p{i}" for i in range(7)], r, w)
+out = [None] * w
+dist.all_gather_object(out, mine)
+dist.barrier()
+if is_main_process():
+    print(json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+def test_prompt_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", str(script), str(ROOT)], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("[[")][-1]
+    shards = json.loads(line)
+    assert shards == [["p0", "p2", "p4", "p6"], ["p1", "p3", "p5"]]
