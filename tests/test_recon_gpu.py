@@ -70,6 +70,12 @@ def test_engine_matches_reference_golden(tiny):
     torch.cuda.synchronize()
     with torch.no_grad():
         ora = R.recon_forward(sd, ocfg, g["latent"], g["image"])
+    _, geo = eng.token_workspace(2, 28, 28)
+    with torch.no_grad():
+        otaps = R.backbone(sd, g["latent"], 1, 2, (28, 28), ocfg.heads, ocfg.n_dino, ocfg.depth)
+    tap_err = [_rel(geo["taps"][i].view(2, geo["Pp"], -1)[:, :geo["P"]], t[0]) for i, t in enumerate(otaps)]
+    print("backbone tap rel err (bf16 GEMM/attention vs fp32 oracle, width 64):", [f"{e:.1e}" for e in tap_err])
+    assert max(tap_err) < 3e-2
     poses = torch.stack([p.cpu() for p in out["pred_pose_enc_list"]])[:, None]
     r_pose = _rel(poses, g["pose_enc_list"])
     r_depth = _rel(out["depth"], g["depth"][0, ..., 0])
