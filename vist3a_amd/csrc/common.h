@@ -22,17 +22,17 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
   return __uint_as_float(((unsigned int)h) << 16);
 }
-// round-to-nearest-even fp32 -> bf16 (NaN preserved as quiet NaN), identical to torch's .to(bfloat16)
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+// fp32 -> bf16, round-to-nearest-even, NaN stays NaN: gfx950 does this in hardware (v_cvt_pk_bf16_f32, two values per
+// instruction); identical to torch's .to(bfloat16).  The (__bf16) cast is what makes hipcc emit it.
+typedef __attribute__((ext_vector_type(2))) __bf16 v3a_bf16x2;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  v3a_bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned int, v);
 }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
 __device__ __forceinline__ void unpack_bf16x8(const u32x4& v, float* f) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
