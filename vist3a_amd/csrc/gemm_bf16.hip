@@ -16,6 +16,7 @@
 //   * workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous run of tiles.
 #include "common.h"
 #include "../../include/vist3a_hip.h"
+#include <type_traits>
 
 namespace {
 
@@ -45,29 +46,46 @@ struct GemmP {
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK, int NS>
 struct TileCfg {
   static constexpr int NW = WM * WN;
   static constexpr int NTHR = NW * 64;
   static constexpr int WTM = BM / WM, WTN = BN / WN;
   static constexpr int MT = WTM / 32, NTL = WTN / 32;
   static constexpr int ROWS = BM + BN;
-  static constexpr int STAGE = ROWS * 128;
-  static constexpr int NL = ROWS / 8 / NW;
+  static constexpr int RB = BK * 2;            // bytes per tile row in LDS
+  static constexpr int CPR = RB / 16;          // 16-B chunks per row (8 or 4)
+  static constexpr int RPI = 64 / CPR;         // rows covered by one 1-KiB DMA instruction (8 or 16)
+  static constexpr int STAGE = ROWS * RB;
+  static constexpr int NINS = ROWS / RPI;      // DMA instructions per stage (whole workgroup)
+  static constexpr int NL = (NINS + NW - 1) / NW;   // ... per wave (upper bound)
+  static constexpr int NLMIN = NINS / NW;           // ... per wave (lower bound: counted vmcnt uses this)
+  static constexpr int NLA = BM / RPI / NW;    // (CONV) instructions of every wave that fall in the A tile
+  static constexpr int KSTEPS = BK / 16;
   static constexpr int PITCH = WTN * 2 + 8;
   static constexpr int EPI_BYTES = NW * WTM * PITCH;
-  static constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
-  static_assert(ROWS % (8 * NW) == 0, "staging rows must divide evenly over waves");
+  static constexpr int LDS_BYTES = (NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
+  static constexpr bool CONV_OK = (BM / RPI) % NW == 0 && NINS % NW == 0;
+  static_assert(BK == 32 || BK == 64, "BK");
+  static_assert(NS >= 2, "ring depth");
+  static_assert(ROWS % RPI == 0 && BM % RPI == 0, "staging instruction must not straddle A/B");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(BM % 32 == 0, "swizzle assumes B rows start at a multiple of 32");
-  static_assert((BM / 8) % NW == 0, "A/B staging split must fall on an instruction boundary");
 };
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+// STG = 0: tiles arrive by LDS-DMA (global_load_lds) into an NS-deep ring.
+// STG = 1: tiles are staged through registers (global_load_dwordx4 -> ds_write_b128, 2 LDS buffers): the loads of slab t+2
+//          are issued, and the slab t+1 registers written to LDS, BETWEEN the MFMA groups of slab t.  An LDS-DMA instruction
+//          occupies its wave for ~100+ cycles at issue and every wave of the workgroup issues them at the same point, so
+//          DMA staging leaves the matrix pipe idle for ~40 % of each slab (measured: 1468 TF without refill vs 830 with).
+template <int BM, int BN, int WM, int WN, int BK, int NS, bool CONV, int STG>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
-  using T = TileCfg<BM, BN, WM, WN>;
+  using T = TileCfg<BM, BN, WM, WN, BK, NS>;
   constexpr int NW = T::NW, MT = T::MT, NTL = T::NTL, NL = T::NL, STAGE = T::STAGE;
   constexpr int WTM = T::WTM, WTN = T::WTN, PITCH = T::PITCH;
+  constexpr int RB = T::RB, CPR = T::CPR, RPI = T::RPI, NINS = T::NINS, KSTEPS = T::KSTEPS;
+  static_assert(!CONV || T::CONV_OK, "conv needs an even A/B instruction split");
+  static_assert(STG == 0 || NS == 2, "register staging uses two LDS buffers");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -80,17 +98,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
   const int t = xcd_remap(blockIdx.x, tilesM * tilesN);
   const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
 
-  // ---- per-lane staging sources (advance by 128 B per K slab) ----
-  constexpr int NLA = (BM / 8 + NW - 1) / NW;  // staging instructions of this wave that can fall in the A tile
+  // ---- per-lane staging sources (advance by RB bytes per K slab) ----
+  constexpr int NLA = T::NLA;
   const char* gp[NL];
+  int ldso[STG == 1 ? NL : 1];
+  u32x4 rg[STG == 1 ? NL : 1];
   int cvt[CONV ? NLA : 1], cvh[CONV ? NLA : 1], cvw[CONV ? NLA : 1], cvc[CONV ? NLA : 1];
   int* ktl = (int*)(smem + T::LDS_BYTES);  // CONV: K-chunk table copied behind the tile ring
+  auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    const int g = j * NW + wave;  // wave-uniform 8-row group
-    const int R = g * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((R >> 1) & 7);
-    if (g * 8 < BM) {
+    const int g = j * NW + wave;  // wave-uniform DMA instruction index = RPI-row group
+    const int R = g * RPI + lane / CPR;
+    // LDS-DMA writes lane-linear, so the swizzle goes on the SOURCE chunk; register staging reads linear and swizzles the
+    // ds_write address instead.  Either way LDS position (R, c') holds global chunk c' ^ swz(R).
+    const int c = STG == 0 ? ((lane % CPR) ^ swz(R)) : (lane % CPR);
+    if (STG == 1) ldso[j] = R * RB + (((lane % CPR) ^ swz(R)) << 4);
+    if (g * RPI < BM) {
       int row = m0 + R;
       row = row < p.M ? row : p.M - 1;
       if constexpr (CONV) {
@@ -116,13 +140,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
     __syncthreads();
   }
   int kslab = 0;
-  auto stage = [&](int s) {
+  // issues this wave's DMA instructions j with j % nparts == part of the slab into ring slot s (the K-loop spreads the
+  // parts between its MFMA groups so that VMEM issue overlaps matrix-pipe time instead of preceding it)
+  auto stage = [&](int s, int part, int nparts) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
+      if (j % nparts != part) continue;
       const int g = j * NW + wave;
+      if (NINS % NW != 0 && g >= NINS) continue;  // ragged last round: wave-uniform skip
       if constexpr (CONV) {
-        if (j < NLA) {  // (BM/8) % NW == 0: instruction j < NLA is an A-tile instruction for every wave
-          const int e = ktl[kslab * 8 + cvc[j]];
+        if (j < NLA) {  // (BM/RPI) % NW == 0: instruction j < NLA is an A-tile instruction for every wave
+          const int e = ktl[kslab * CPR + cvc[j]];
           int tt = cvt[j] + ((e >> 24) & 15), hh = cvh[j] + ((e >> 20) & 15), ww = cvw[j] + ((e >> 16) & 15);
           const int eH = p.ups ? p.cH * 2 : p.cH, eW = p.ups ? p.cW * 2 : p.cW;
           bool ok = e < 0;  // bit 31 = valid chunk
@@ -140,9 +168,46 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
         }
       }
       glds16(gp[j], smem + s * STAGE + g * 1024);
-      gp[j] += 128;
+      gp[j] += RB;
+    }
+    if (part == nparts - 1) ++kslab;
+  };
+  auto load_regs = [&]() {  // STG == 1: this wave's share of the next slab -> registers (compiler-counted vmcnt)
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int g = j * NW + wave;
+      if (NINS % NW != 0 && g >= NINS) continue;
+      if constexpr (CONV) {
+        if (j < NLA) {
+          const int e = ktl[kslab * CPR + cvc[j]];
+          int tt = cvt[j] + ((e >> 24) & 15), hh = cvh[j] + ((e >> 20) & 15), ww = cvw[j] + ((e >> 16) & 15);
+          const int eH = p.ups ? p.cH * 2 : p.cH, eW = p.ups ? p.cW * 2 : p.cW;
+          bool ok = e < 0;
+          if (p.replicate) {
+            tt = tt < 0 ? 0 : (tt >= p.cT ? p.cT - 1 : tt);
+            hh = hh < 0 ? 0 : (hh >= eH ? eH - 1 : hh);
+            ww = ww < 0 ? 0 : (ww >= eW ? eW - 1 : ww);
+          } else {
+            ok = ok && tt >= 0 && tt < p.cT && hh >= 0 && hh < eH && ww >= 0 && ww < eW;
+          }
+          if (p.ups) { hh >>= 1; ww >>= 1; }
+          const char* src = p.A + (((size_t)(tt * p.cH + hh) * p.cW + ww) * p.cCin + (e & 0xffff)) * 2;
+          rg[j] = *(const u32x4*)(ok ? src : (const char*)&g_zero16);
+          continue;
+        }
+      }
+      rg[j] = *(const u32x4*)gp[j];
+      gp[j] += RB;
     }
     ++kslab;
+  };
+  auto write_lds = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int g = j * NW + wave;
+      if (NINS % NW != 0 && g >= NINS) continue;
+      *(u32x4*)(smem + s * STAGE + ldso[j]) = rg[j];
+    }
   };
 
   f32x16 acc[MT][NTL];
@@ -153,39 +218,103 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int sw = (lane >> 1) & 7;
-  int koff[4];
+  const int sw = swz(l31);
+  int koff[KSTEPS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + hi) ^ sw) << 4);
-  const int aoff = (wm * WTM) * 128, boff = (BM + wn * WTN) * 128;
+  for (int ks = 0; ks < KSTEPS; ++ks) koff[ks] = l31 * RB + (((2 * ks + hi) ^ sw) << 4);
+  const int aoff = (wm * WTM) * RB, boff = (BM + wn * WTN) * RB;
 
-  const int nk = p.K / 64;
-  stage(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1);
-    const char* sA = smem + cur * STAGE + aoff;
-    const char* sB = smem + cur * STAGE + boff;
+  const int nk = p.K / BK;
+  if constexpr (STG == 0) {
+  // NS-deep LDS ring fed by LDS-DMA.  Slabs kt+1 .. kt+NS-2 stay in flight ACROSS the barrier (counted vmcnt, raw
+  // s_barrier): the DMA latency (~1 us under load) is covered by NS-2 slabs of MFMA work instead of one.
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nk) stage(s0, 0, 1);
+  int slot = 0, fill = NS - 1;
+  // one K slab: wait for its DMA (counted), barrier, then MFMA groups with the refill DMA spread between them
+  auto slab = [&](auto more_tag, auto drain_tag) {
+    constexpr bool MORE = decltype(more_tag)::value, DRAIN = decltype(drain_tag)::value;
+    if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::NLMIN * (NS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();  // slab visible to all waves; everyone is done reading the slot about to be refilled
+    if constexpr (MORE) stage(fill, 0, 1);  // measured: issuing the refill up front beats spreading it between MFMA groups
+    const char* sA = smem + slot * STAGE + aoff;
+    const char* sB = smem + slot * STAGE + boff;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
       bf16x8 a[MT], b[NTL];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *(const bf16x8*)(sA + i * 4096 + koff[ks]);
+      for (int i = 0; i < MT; ++i) a[i] = *(const bf16x8*)(sA + i * 32 * RB + koff[ks]);
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) b[j] = *(const bf16x8*)(sB + j * 4096 + koff[ks]);
+      for (int j = 0; j < NTL; ++j) b[j] = *(const bf16x8*)(sB + j * 32 * RB + koff[ks]);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTL; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    slot = slot + 1 == NS ? 0 : slot + 1;
+    fill = fill + 1 == NS ? 0 : fill + 1;
+  };
+  using TT = std::true_type;
+  using FF = std::false_type;
+  int kt = 0;
+  for (; kt + NS - 1 < nk; ++kt) slab(TT{}, FF{});   // steady state: refill in flight, NS-2 later slabs outstanding
+  for (; kt < nk; ++kt) slab(FF{}, TT{});            // tail: nothing left to issue, drain
+  } else {
+    // register-staged pipeline, two LDS buffers
+    auto mma_step = [&](const char* sA, const char* sB, int ks) {
+      bf16x8 a[MT], b[NTL];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *(const bf16x8*)(sA + i * 32 * RB + koff[ks]);
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) b[j] = *(const bf16x8*)(sB + j * 32 * RB + koff[ks]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    };
+    load_regs();
+    write_lds(0);
+    if (nk > 1) load_regs();
+    __syncthreads();
+    auto slab = [&](int cur, auto write_tag, auto load_tag) {
+      const char* sA = smem + cur * STAGE + aoff;
+      const char* sB = smem + cur * STAGE + boff;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        mma_step(sA, sB, ks);
+        if (ks == KSTEPS - 2) {
+          // slab t+1: registers -> the buffer read during slab t-1 (the loads had a whole slab of MFMA time to land) ...
+          if constexpr (decltype(write_tag)::value) write_lds(cur ^ 1);
+          // ... and at once re-issue the same registers for slab t+2 (consumed one slab from now)
+          if constexpr (decltype(load_tag)::value) { load_regs(); __builtin_amdgcn_sched_barrier(0); }
+        }
+      }
+      __syncthreads();
+    };
+    using TT = std::true_type;
+    using FF = std::false_type;
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) slab(kt & 1, TT{}, TT{});
+    if (kt + 1 < nk) { slab(kt & 1, TT{}, FF{}); ++kt; }
+    if (kt < nk) slab(kt & 1, FF{}, FF{});
   }
+  if constexpr (STG == 0) __builtin_amdgcn_s_barrier();  // all fragment reads retired before the ring is reused by the epilogue
 
+  if (p.flags & (1 << 29)) {  // DEBUG/profiling only: skip the epilogue (accumulators kept live by a never-taken store)
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 123456.789f) ((float*)p.C)[tid] = sum;
+    return;
+  }
   // ---- epilogue phase 1: acc + bias -> bf16 -> this wave's private LDS region ----
   char* reg = smem + wave * (WTM * PITCH);
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
@@ -246,6 +375,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
     const u32x2 lo = *(const u32x2*)(reg + ml * PITCH + ch * 16);
     const u32x2 hi2 = *(const u32x2*)(reg + ml * PITCH + ch * 16 + 8);
     if (m >= p.M || n >= p.N) continue;
+    if (p.flags & (1 << 30)) continue;  // DEBUG/profiling only: phase 2 without global traffic
     u32x4 raw;
     raw[0] = lo[0]; raw[1] = lo[1]; raw[2] = hi2[0]; raw[3] = hi2[1];
     float v[8];
@@ -318,28 +448,45 @@ struct TileEntry {
   gemm_fn fn, conv_fn;
 };
 
-#define TILE_ENTRY(BM, BN, WM, WN)                                                   \
-  { #BM "x" #BN "_w" #WM "x" #WN, BM, BN, TileCfg<BM, BN, WM, WN>::NTHR,            \
-    TileCfg<BM, BN, WM, WN>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, false>, \
-    (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, true> }
+template <int BM, int BN, int WM, int WN, int BK, int NS, int STG>
+constexpr gemm_fn conv_kernel_or_null() {
+  if constexpr (TileCfg<BM, BN, WM, WN, BK, NS>::CONV_OK) return (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, true, STG>;
+  else return nullptr;
+}
+#define TILE_ENTRY_S(BM, BN, WM, WN, BK, NS, STG)                                                   \
+  { #BM "x" #BN "_w" #WM "x" #WN "_k" #BK "s" #NS "_stg" #STG, BM, BN, TileCfg<BM, BN, WM, WN, BK, NS>::NTHR, \
+    TileCfg<BM, BN, WM, WN, BK, NS>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, false, STG>, \
+    conv_kernel_or_null<BM, BN, WM, WN, BK, NS, STG>() }
+#define TILE_ENTRY(BM, BN, WM, WN, BK, NS) TILE_ENTRY_S(BM, BN, WM, WN, BK, NS, 0)
 
 const TileEntry kTiles[] = {
-    TILE_ENTRY(256, 192, 4, 2),  // 0: N % 192 == 0 shapes (d=1536): 8192x1536 -> exactly 256 tiles
-    TILE_ENTRY(192, 256, 2, 4),  // 1: transposed role of 0 (V^T = Wv . X^T)
-    TILE_ENTRY(256, 256, 2, 4),  // 2
-    TILE_ENTRY(128, 256, 2, 4),  // 3
-    TILE_ENTRY(256, 128, 4, 2),  // 4
-    TILE_ENTRY(128, 128, 2, 2),  // 5: small / ragged problems, 2 workgroups per CU
+    TILE_ENTRY(256, 192, 4, 2, 64, 2),  // 0: N % 192 == 0 shapes (d=1536): 8192x1536 -> exactly 256 tiles
+    TILE_ENTRY(192, 256, 2, 4, 64, 2),  // 1: transposed role of 0 (V^T = Wv . X^T)
+    TILE_ENTRY(256, 256, 2, 4, 64, 2),  // 2
+    TILE_ENTRY(128, 256, 2, 4, 64, 2),  // 3
+    TILE_ENTRY(256, 128, 4, 2, 64, 2),  // 4
+    TILE_ENTRY(128, 128, 2, 2, 64, 2),  // 5: small / ragged problems, 2 workgroups per CU
+    // tuning variants (explicit `tile` only)
+    TILE_ENTRY(256, 192, 4, 2, 32, 5),    // 6: BK=32 slabs, 5-deep ring (4 slabs in flight)
+    TILE_ENTRY_S(256, 192, 4, 2, 64, 2, 1),  // 7: register-staged (global_load -> ds_write) instead of LDS-DMA
+    TILE_ENTRY_S(256, 256, 2, 4, 64, 2, 1),  // 8
+    TILE_ENTRY(256, 256, 2, 2, 64, 2),    // 9: 4 waves, 128x128 per wave (one wave per SIMD, 0.5 LDS reads per MFMA)
+    TILE_ENTRY(256, 192, 2, 2, 64, 2),    // 10: 4 waves, 128x96 per wave
+    TILE_ENTRY(192, 256, 2, 2, 64, 2),    // 11: 4 waves, 96x128 per wave
+    TILE_ENTRY_S(256, 256, 2, 2, 64, 2, 1),  // 12
+    TILE_ENTRY_S(256, 192, 2, 2, 64, 2, 1),  // 13
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 int g_attr_lds[kNumTiles][2] = {};
 
-int pick_tile(int M, int N) {
+constexpr int kAutoTiles = 6;  // tiles the heuristic may choose from (the rest are explicit / tuning variants)
+int pick_tile(int M, int N, bool conv = false) {
   // minimise (#rounds over 256 CUs) x (tile area incl. padding waste); prefer bigger tiles on ties.
   double best = 1e30;
-  int bi = kNumTiles - 1;
-  for (int i = 0; i < kNumTiles; ++i) {
+  int bi = 5;
+  for (int i = 0; i < kAutoTiles; ++i) {
     const TileEntry& e = kTiles[i];
+    if (conv && !e.conv_fn) continue;
     long tm = (M + e.BM - 1) / e.BM, tn = (N + e.BN - 1) / e.BN;
     long tiles = tm * tn;
     int per_cu = (e.lds <= 80 * 1024) ? 2 : 1;
@@ -354,9 +501,10 @@ int pick_tile(int M, int N) {
 }
 
 int launch(const GemmP& p, int ti, bool conv, void* stream) {
-  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N);
+  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N, conv);
   const TileEntry& e = kTiles[ti];
   const gemm_fn fn = conv ? e.conv_fn : e.fn;
+  if (!fn) return V3A_ERR_ARG;  // this tile shape has no conv instantiation
   const int lds = e.lds + (conv ? p.K / 8 * 4 : 0);
   if (lds > 160 * 1024) return V3A_ERR_SHAPE;
   if (g_attr_lds[ti][conv] < lds) {

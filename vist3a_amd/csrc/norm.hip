@@ -71,12 +71,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd;
     if (p.w) {
+      const f32x4 w0 = *(const f32x4*)(p.w + c * 8), w1 = *(const f32x4*)(p.w + c * 8 + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = o[e] * p.w[c * 8 + e] + (p.b ? p.b[c * 8 + e] : 0.f);
+      for (int e = 0; e < 4; ++e) { o[e] *= w0[e]; o[4 + e] *= w1[e]; }
+      if (p.b) {
+        const f32x4 b0 = *(const f32x4*)(p.b + c * 8), b1 = *(const f32x4*)(p.b + c * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] += b0[e]; o[4 + e] += b1[e]; }
+      }
     }
     if (p.scale) {
+      const f32x4 s0 = *(const f32x4*)(p.scale + moff + c * 8), s1 = *(const f32x4*)(p.scale + moff + c * 8 + 4);
+      const f32x4 h0 = *(const f32x4*)(p.shift + moff + c * 8), h1 = *(const f32x4*)(p.shift + moff + c * 8 + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = o[e] * (1.f + p.scale[moff + c * 8 + e]) + p.shift[moff + c * 8 + e];
+      for (int e = 0; e < 4; ++e) { o[e] = o[e] * (1.f + s0[e]) + h0[e]; o[4 + e] = o[4 + e] * (1.f + s1[e]) + h1[e]; }
     }
     if (p.y_f32) {
       float* yp = (float*)p.y + orow * p.ldy + c * 8;
@@ -125,8 +133,11 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const RmsP p) {
     const int c = lane + i * 64;
     if (c >= nch) continue;
     float o[8];
+    {
+      const f32x4 w0 = *(const f32x4*)(p.w + c * 8), w1 = *(const f32x4*)(p.w + c * 8 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = v[i][e] * rs * p.w[c * 8 + e];
+      for (int e = 0; e < 4; ++e) { o[e] = v[i][e] * rs * w0[e]; o[4 + e] = v[i][4 + e] * rs * w1[e]; }
+    }
     if (p.rope) {
       const float* rp = p.rope + ((size_t)tok * (p.hd >> 1) + (size_t)(c % cph) * 4) * 2;
       const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
@@ -185,10 +196,12 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const RowNormP p) {
     const int c = j + i * lpr;
     if (c >= nch) continue;
     float o[8];
+    const f32x4 w0 = *(const f32x4*)(p.w + c * 8), w1 = *(const f32x4*)(p.w + c * 8 + 4);
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    if (p.b) { b0 = *(const f32x4*)(p.b + c * 8); b1 = *(const f32x4*)(p.b + c * 8 + 4); }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t = v[i][e] * rs * p.w[c * 8 + e];
-      if (p.b) t += p.b[c * 8 + e];
+      float t = v[i][e] * rs * (e < 4 ? w0[e & 3] : w1[e & 3]) + (e < 4 ? b0[e & 3] : b1[e & 3]);
       if (p.act == V3A_ACT_SILU) t = silu(t);
       o[e] = t;
     }
