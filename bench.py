@@ -26,6 +26,22 @@ import torch
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*/pmc_traffic.json, produced by
+    tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied).  bench.py cannot run rocprofv3
+    around itself, so this is the value of the same command profiled at round time; null if the file is absent."""
+    best = None
+    for f in sorted(ROOT.glob("profiles/*/pmc_traffic.json")):
+        try:
+            k = json.loads(f.read_text())["kernels"]
+            for name, v in k.items():
+                if name.replace(" ", "").startswith(kernel_key):
+                    best = v["hbm_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            pass
+    return best
+
+
 def dit_flops_per_forward(N, d, ffn, L, ctx=512):
     """projections + attention + FFN, multiply-add = 2."""
     return L * (8 * N * d * d + 4 * N * N * d + (4 * N * d * d + 4 * ctx * d * d) + 4 * N * ctx * d + 4 * N * d * ffn)
@@ -140,9 +156,10 @@ def main():
                        "stage_ms_last_scene": {"denoise": round(stage.denoise_ms, 1), "vae_decode+resize": round(stage.vae_ms, 1),
                                                "stitch+recon": round(stage.recon_ms, 1)},
                        "dit_model_tflops_per_s": round(2 * a.denoise_steps * fwd_flops / (stage.denoise_ms * 1e-3) / 1e12, 1)},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<{lib.load().v3a_gemm_tile_name(dom_tile).decode()}> (bf16 MFMA 32x32x16)",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<{lib.load().v3a_gemm_tile_name(dom_tile).decode()}> = gemm_nt_kernel<256,192,4,2,64,2,false,0> (bf16 MFMA 32x32x16)",
                          "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "launches_timed": ps["launches"], "avg_launch_ms": round(ps["avg_ms"], 4),
+                         "traffic": pmc_traffic("gemm_nt_kernel<256,192,4,2,64,2,false,0>"), "traffic_unit": "bytes/launch (PMC, profiles/)",
+                         "launches_timed": ps["launches"], "avg_launch_ms": round(ps["avg_ms"], 4),
                          "flops_per_launch": ps["flops_per_launch"]},
         }
         if world == 1 and not a.no_cpu_baseline:
