@@ -63,7 +63,7 @@ struct TileCfg {
   static constexpr int NLA = BM / RPI / NW;    // (CONV) instructions of every wave that fall in the A tile
   static constexpr int KSTEPS = BK / 16;
   static constexpr int PITCH = WTN * 2 + 8;
-  static constexpr int EPI_BYTES = NW * WTM * PITCH;
+  static constexpr int EPI_BYTES = NW * 32 * PITCH;   // the epilogue parks one 32-row group per wave at a time
   static constexpr int LDS_BYTES = (NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
   static constexpr bool CONV_OK = (BM / RPI) % NW == 0 && NINS % NW == 0;
   static_assert(BK == 32 || BK == 64, "BK");
@@ -78,8 +78,10 @@ struct TileCfg {
 //          are issued, and the slab t+1 registers written to LDS, BETWEEN the MFMA groups of slab t.  An LDS-DMA instruction
 //          occupies its wave for ~100+ cycles at issue and every wave of the workgroup issues them at the same point, so
 //          DMA staging leaves the matrix pipe idle for ~40 % of each slab (measured: 1468 TF without refill vs 830 with).
-template <int BM, int BN, int WM, int WN, int BK, int NS, bool CONV, int STG>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
+// OCC = workgroups the kernel is compiled to co-reside per CU (register cap = 512 / (OCC * waves per SIMD)): with OCC = 2
+// one workgroup's epilogue / DMA-issue bubbles are filled by the other's MFMAs.
+template <int BM, int BN, int WM, int WN, int BK, int NS, bool CONV, int STG, int OCC = 1>
+__global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_kernel(const GemmP p) {
   using T = TileCfg<BM, BN, WM, WN, BK, NS>;
   constexpr int NW = T::NW, MT = T::MT, NTL = T::NTL, NL = T::NL, STAGE = T::STAGE;
   constexpr int WTM = T::WTM, WTN = T::WTN, PITCH = T::PITCH;
@@ -315,60 +317,62 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
     if (sum == 123456.789f) ((float*)p.C)[tid] = sum;
     return;
   }
-  // ---- epilogue phase 1: acc + bias -> bf16 -> this wave's private LDS region ----
-  char* reg = smem + wave * (WTM * PITCH);
-  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+  // ---- epilogue: per 32-row group of the wave tile:
+  //   phase 1: acc + bias -> bf16 -> this wave's private LDS region (32 rows x WTN)
+  //   phase 2: whole-row re-read, fused elementwise, 16-byte coalesced stores
+  char* reg = smem + wave * (32 * PITCH);
+  const int mw0 = m0 + wm * WTM, nw = n0 + wn * WTN;
   const bool bias_row = (p.flags & V3A_GEMM_BIAS_ROW) != 0;
+  constexpr int CH = WTN / 8;
+  constexpr int ITERS = 32 * CH / 64;
+  static_assert((32 * CH) % 64 == 0, "epilogue chunking");
+  const int act = p.act, flags = p.flags;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int ml = i * 32 + l31;
-    float brow = 0.f;
-    if (p.bias && bias_row) {
-      int m = mw + ml;
-      brow = p.bias[m < p.M ? m : p.M - 1];
-    }
+    const int mw = mw0 + i * 32;
+    {
+      const int ml = l31;
+      float brow = 0.f;
+      if (p.bias && bias_row) {
+        int m = mw + ml;
+        brow = p.bias[m < p.M ? m : p.M - 1];
+      }
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) {
+      for (int j = 0; j < NTL; ++j) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + g * 8 + hi * 4;
-        float v[4];
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + g * 8 + hi * 4;
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
-        if (p.bias) {
-          if (bias_row) {
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+          if (p.bias) {
+            if (bias_row) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += brow;
-          } else {
-            const int n = nw + nl;
-            if (n + 3 < p.N) {
-              const f32x4 bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += bv[e];
+              for (int e = 0; e < 4; ++e) v[e] += brow;
             } else {
+              const int n = nw + nl;
+              if (n + 3 < p.N) {
+                const f32x4 bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n + e < p.N) v[e] += p.bias[n + e];
+                for (int e = 0; e < 4; ++e) v[e] += bv[e];
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (n + e < p.N) v[e] += p.bias[n + e];
+              }
             }
           }
+          u32x2 pk;
+          pk[0] = pack_bf16x2(v[0], v[1]);
+          pk[1] = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)(reg + ml * PITCH + nl * 2) = pk;
         }
-        u32x2 pk;
-        pk[0] = pack_bf16x2(v[0], v[1]);
-        pk[1] = pack_bf16x2(v[2], v[3]);
-        *(u32x2*)(reg + ml * PITCH + nl * 2) = pk;
       }
     }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-
-  // ---- epilogue phase 2: whole-row re-read, fused elementwise, 16-byte coalesced stores ----
-  constexpr int CH = WTN / 8;
-  constexpr int ITERS = WTM * CH / 64;
-  static_assert((WTM * CH) % 64 == 0, "epilogue chunking");
-  const int act = p.act, flags = p.flags;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
-  for (int it = 0; it < ITERS; ++it) {
+    for (int it = 0; it < ITERS; ++it) {
     const int idx = it * 64 + lane;
     const int ml = idx / CH, ch = idx % CH;
     const int m = mw + ml, n = nw + ch * 8;
@@ -439,6 +443,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(const GemmP p) {
       *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = pack_bf16x8(v);
     }
   }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this group's reads returned before the next group overwrites the region
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 typedef void (*gemm_fn)(const GemmP);
@@ -458,6 +465,9 @@ constexpr gemm_fn conv_kernel_or_null() {
     TileCfg<BM, BN, WM, WN, BK, NS>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, false, STG>, \
     conv_kernel_or_null<BM, BN, WM, WN, BK, NS, STG>() }
 #define TILE_ENTRY(BM, BN, WM, WN, BK, NS) TILE_ENTRY_S(BM, BN, WM, WN, BK, NS, 0)
+#define TILE_ENTRY_OCC(BM, BN, WM, WN, BK, NS, OCC)                                                 \
+  { #BM "x" #BN "_w" #WM "x" #WN "_k" #BK "s" #NS "_occ" #OCC, BM, BN, TileCfg<BM, BN, WM, WN, BK, NS>::NTHR, \
+    TileCfg<BM, BN, WM, WN, BK, NS>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, false, 0, OCC>, nullptr }
 
 const TileEntry kTiles[] = {
     TILE_ENTRY(256, 192, 4, 2, 64, 2),  // 0: N % 192 == 0 shapes (d=1536): 8192x1536 -> exactly 256 tiles
@@ -466,20 +476,17 @@ const TileEntry kTiles[] = {
     TILE_ENTRY(128, 256, 2, 4, 64, 2),  // 3
     TILE_ENTRY(256, 128, 4, 2, 64, 2),  // 4
     TILE_ENTRY(128, 128, 2, 2, 64, 2),  // 5: small / ragged problems, 2 workgroups per CU
-    // tuning variants (explicit `tile` only)
-    TILE_ENTRY(256, 192, 4, 2, 32, 5),    // 6: BK=32 slabs, 5-deep ring (4 slabs in flight)
-    TILE_ENTRY_S(256, 192, 4, 2, 64, 2, 1),  // 7: register-staged (global_load -> ds_write) instead of LDS-DMA
-    TILE_ENTRY_S(256, 256, 2, 4, 64, 2, 1),  // 8
-    TILE_ENTRY(256, 256, 2, 2, 64, 2),    // 9: 4 waves, 128x128 per wave (one wave per SIMD, 0.5 LDS reads per MFMA)
-    TILE_ENTRY(256, 192, 2, 2, 64, 2),    // 10: 4 waves, 128x96 per wave
-    TILE_ENTRY(192, 256, 2, 2, 64, 2),    // 11: 4 waves, 96x128 per wave
-    TILE_ENTRY_S(256, 256, 2, 2, 64, 2, 1),  // 12
-    TILE_ENTRY_S(256, 192, 2, 2, 64, 2, 1),  // 13
+    // two (or four) co-resident workgroups per CU: one's epilogue / DMA-issue bubbles are filled by the others' MFMAs
+    TILE_ENTRY_OCC(256, 192, 4, 2, 32, 2, 2),  // 6: 56 KiB ring; +14 % on shapes with >= 2 tiles per CU (QK, FFN1)
+    TILE_ENTRY_OCC(128, 192, 2, 2, 32, 2, 4),  // 7: 40 KiB, 4 waves, up to 4 per CU
+    TILE_ENTRY_OCC(128, 192, 2, 2, 64, 2, 2),  // 8: 80 KiB, 4 waves, 2 per CU
+    TILE_ENTRY_OCC(192, 128, 2, 2, 32, 2, 4),  // 9
+    TILE_ENTRY_OCC(192, 256, 2, 4, 32, 2, 2),  // 10: transposed role of 6
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 int g_attr_lds[kNumTiles][2] = {};
 
-constexpr int kAutoTiles = 6;  // tiles the heuristic may choose from (the rest are explicit / tuning variants)
+constexpr int kAutoTiles = 7;  // tiles the heuristic may choose from (the rest are explicit / tuning variants)
 int pick_tile(int M, int N, bool conv = false) {
   // minimise (#rounds over 256 CUs) x (tile area incl. padding waste); prefer bigger tiles on ties.
   double best = 1e30;
@@ -494,6 +501,7 @@ int pick_tile(int M, int N, bool conv = false) {
     long rounds = (tiles + slots - 1) / slots;
     // co-resident small tiles run ~concurrently: cost per round ~ per_cu tiles' area, small efficiency bonus for large tiles
     double eff = (e.BM * e.BN >= 256 * 192) ? 1.0 : (e.BM * e.BN >= 128 * 256 ? 0.9 : 0.8);
+    if (i == 6) eff = 1.06;  // 256x192 two-per-CU: measured +5..14 % over tile 0 once every CU holds two workgroups
     double cost = (double)rounds * per_cu * e.BM * e.BN / eff;
     if (cost < best - 1e-9) { best = cost; bi = i; }
   }
