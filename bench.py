@@ -156,9 +156,9 @@ def main():
                        "stage_ms_last_scene": {"denoise": round(stage.denoise_ms, 1), "vae_decode+resize": round(stage.vae_ms, 1),
                                                "stitch+recon": round(stage.recon_ms, 1)},
                        "dit_model_tflops_per_s": round(2 * a.denoise_steps * fwd_flops / (stage.denoise_ms * 1e-3) / 1e12, 1)},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<{lib.load().v3a_gemm_tile_name(dom_tile).decode()}> = gemm_nt_kernel<256,192,4,2,64,2,false,0> (bf16 MFMA 32x32x16)",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<{lib.load().v3a_gemm_tile_name(dom_tile).decode()}> (bf16 MFMA 32x32x16)",
                          "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic("gemm_nt_kernel<256,192,4,2,64,2,false,0>"), "traffic_unit": "bytes/launch (PMC, profiles/)",
+                         "traffic": pmc_traffic("gemm_nt_kernel<256,192,4,2,64,2,false,0"), "traffic_unit": "bytes/launch (PMC, profiles/)",
                          "launches_timed": ps["launches"], "avg_launch_ms": round(ps["avg_ms"], 4),
                          "flops_per_launch": ps["flops_per_launch"]},
         }
