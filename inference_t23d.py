@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import os
 import sys
+import zlib
 from pathlib import Path
 
 import torch
@@ -49,22 +50,30 @@ def main(args):
     device = torch.device(f"cuda:{rank % torch.cuda.device_count()}")
     torch.cuda.set_device(device)
     with open(args.input_texts_path, "r") as f:
-        prompts = shard_prompts([line.strip() for line in f.readlines()], rank, world)
+        prompts = [line.strip() for line in f.readlines()]
+    coop = args.scene_parallel and world > 1
+    if not coop:  # the reference's split: whole prompts per rank, no collective
+        prompts = shard_prompts(prompts, rank, world)
     gen = torch.Generator().manual_seed(12413)  # seed_everything(12413): one stream per process, consumed in prompt order
     transformer = build_transformer(args, device)
     stitched = load_stitching_model(args)
     scene = Text23DGS(transformer, stitched.diffusion_vae, stitched, flow_shift=args.flow_shift,
                       feedforward_resolution=args.feedforward_resolution, device=device)
+    if coop:  # every rank works on the same prompt: CFG-parallel x sequence-parallel denoise, rank 0 writes
+        from vist3a_amd.wan.seqpar import DenoisePlan
+        scene.pipe.plan = DenoisePlan.from_dist()
     embeds = torch.load(args.text_embeds_path, map_location="cpu") if args.text_embeds_path else None
     for prompt in prompts:
         if embeds is not None:
             pe, ne = embeds[PROMPT_TEMPLATE.format(prompt)][None].to(device), embeds["__negative__"][None].to(device)
         elif args.synthetic_text:
-            pe, ne = synthetic_text_embeddings(device, seed=abs(hash(prompt)) % (2 ** 31))
+            pe, ne = synthetic_text_embeddings(device, seed=zlib.crc32(prompt.encode()) % (2 ** 31))
         else:
             raise RuntimeError("no text encoder on this path: pass --text_embeds_path (precomputed UMT5 embeddings) or --synthetic_text")
         out, _, _ = scene.generate(pe, ne, generator=gen, num_frames=args.num_frames, num_inference_steps=args.num_inference_steps,
                                    guidance_scale=float(args.cfg_scale), height=args.resolution, width=args.resolution)
+        if coop and rank != 0:
+            continue
         save = Path(args.output_dir) / prompt[:100].replace("/", "")
         os.makedirs(save, exist_ok=args.overwrite)  # the reference raises when the directory exists (inference_t23d.py:126)
         (save / "prompt.txt").write_text(prompt)

@@ -96,3 +96,72 @@ def test_prompt_sharding_world_size_2_gloo(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("[[")][-1]
     shards = json.loads(line)
     assert shards == [["p0", "p2", "p4", "p6"], ["p1", "p3", "p5"]]
+
+
+_SP_WORKER = '''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from vist3a_amd.utils.dist_util import setup_dist
+from vist3a_amd.wan.seqpar import DenoisePlan
+setup_dist("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+plan = DenoisePlan.from_dist()
+ok = plan.sp is None and plan.cfg is not None and plan.cfg.rank == r and plan.cfg.world == 2
+# the cond/uncond exchange of one step: each rank contributes its branch, both see [cond, uncond]
+mine = torch.full((1, 4, 2, 3, 3), float(r + 1), dtype=torch.bfloat16)
+pair = torch.empty((2,) + tuple(mine.shape), dtype=torch.bfloat16)
+plan.cfg.all_gather(pair, mine).wait()
+ok = ok and bool((pair[0] == 1).all()) and bool((pair[1] == 2).all())
+# K|V^T slab exchange as the DiT does it (B=2 batch items, Nl=8 local tokens, d=4), reassembled to [B,N,d] / [d,B,N]
+from vist3a_amd.wan.seqpar import DistGroup
+spg = DistGroup([0, 1], r, dist.group.WORLD)
+B, Nl, d, P = 2, 8, 4, 2
+N = P * Nl
+K = torch.arange(B * N * d, dtype=torch.float32).view(B, N, d)
+Vt = -torch.arange(d * B * N, dtype=torch.float32).view(d, B, N)
+kl = K[:, r * Nl:(r + 1) * Nl].reshape(B * Nl, d)
+vtl = Vt[:, :, r * Nl:(r + 1) * Nl].reshape(d, B * Nl)
+pack = torch.cat([kl.reshape(-1), vtl.reshape(-1)])
+gbuf = torch.empty(P, pack.numel())
+spg.all_gather(gbuf, pack).wait()
+Ml = B * Nl
+kfull = gbuf[:, :Ml * d].view(P, B, Nl, d).permute(1, 0, 2, 3).reshape(B, N, d)
+vfull = gbuf[:, Ml * d:].view(P, d, B, Nl).permute(1, 2, 0, 3).reshape(d, B, N)
+ok = ok and torch.equal(kfull, K) and torch.equal(vfull, Vt)
+res = [None] * w
+dist.all_gather_object(res, bool(ok))
+if r == 0:
+    print(json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+def test_denoise_plan_world_size_2_gloo(tmp_path):
+    """wan/seqpar.py over a real 2-process group: plan layout, the per-step CFG exchange and the K|V^T slab all-gather
+    with the exact reassembly permutations WanDiT.forward applies."""
+    script = tmp_path / "sp.py"
+    script.write_text(_SP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29633", str(script), str(ROOT)], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("[")][-1]
+    assert json.loads(line) == [True, True]
+
+
+def test_denoise_plan_layouts():
+    from vist3a_amd.wan.seqpar import DenoisePlan, ThreadWorld
+    assert [DenoisePlan.layout(w) for w in (1, 2, 3, 4, 8)] == [(1, 1), (2, 1), (1, 3), (2, 2), (2, 4)]
+    plans = DenoisePlan.from_threads(8)
+    assert [(p.cfg.rank, p.sp.rank, p.sp.world) for p in plans] == [(c, s, 4) for c in range(2) for s in range(4)]
+    w = ThreadWorld(3)
+    out = w.run(lambda r: [int(v) for v in _gather_cpu(w.group(r), r)])
+    assert out == [[0, 10, 20]] * 3
+
+
+def _gather_cpu(group, r):
+    o = torch.empty(group.world, 1)
+    group.all_gather(o, torch.tensor([10.0 * r])).wait()
+    return o.view(-1)

@@ -36,6 +36,8 @@ def inference_vist3a_argument() -> argparse.ArgumentParser:
     g.add_argument("--text_embeds_path", type=str, default=None,
                    help="torch file {prompt: [512,4096] embedding, '__negative__': ...}; UMT5-XXL itself is outside this path (SURVEY §8f)")
     g.add_argument("--synthetic_text", action="store_true", help="seeded synthetic text embeddings (weights-free smoke runs)")
+    g.add_argument("--scene_parallel", action="store_true",
+                   help="all ranks cooperate on each prompt (CFG-parallel x sequence-parallel DiT over RCCL) instead of striding prompts")
     g.add_argument("--overwrite", action="store_true", help="reuse an existing output directory (the reference raises)")
     return p
 

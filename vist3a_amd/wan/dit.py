@@ -17,6 +17,7 @@ MI355X-first choices (none of them inherited from the PyTorch module graph):
 from __future__ import annotations
 
 import math
+import threading
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -87,19 +88,29 @@ def merge_lora_into_state_dict(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, t
 
 
 class _Workspace:
-    def __init__(self, B: int, N: int, cfg: WanDiTConfig, device):
-        d, M = cfg.dim, B * N
+    """Activation buffers for B batch items of Nl LOCAL tokens attending to N keys (Nl == N unless sequence-parallel)."""
+
+    def __init__(self, B: int, Nl: int, N: int, P: int, cfg: WanDiTConfig, device):
+        d, M = cfg.dim, B * Nl
         e = lambda *s, dt=bf16: torch.empty(*s, device=device, dtype=dt)
-        self.B, self.N, self.M = B, N, M
+        self.B, self.N, self.M = B, Nl, M
         self.x = e(M, d)
         self.n = e(M, d)
-        self.qk = e(M, 2 * d)
-        self.vt = torch.zeros(d, B * ((N + 63) // 64 * 64), device=device, dtype=bf16)
         self.q2 = e(M, d)
         self.ao = e(M, d)
         self.h = e(M, cfg.ffn_dim)
         self.tok = e(M, cfg.in_channels * math.prod(cfg.patch_size))
         self.out = e(M, cfg.out_channels * math.prod(cfg.patch_size))
+        if P == 1:
+            self.qk = e(M, 2 * d)
+            self.vt = torch.zeros(d, B * ((N + 63) // 64 * 64), device=device, dtype=bf16)
+        else:  # sequence-parallel: local q, packed local [K | V^T] to send, gathered slabs, full K / V^T
+            self.q = e(M, d)
+            self.pack = e(2 * M * d)
+            self.gbuf = e(P, 2 * M * d)
+            self.kfull = e(B * N, d)
+            self.vt = torch.zeros(d, B * N + 64, device=device, dtype=bf16)
+            self.ogather = e(P, M * self.out.shape[1])
 
 
 class WanDiT:
@@ -112,8 +123,7 @@ class WanDiT:
         self.dtype = bf16
         self._ws: Dict[tuple, _Workspace] = {}
         self._rope: Dict[tuple, torch.Tensor] = {}
-        self._ctx_key = None
-        self._ctx = None
+        self._ctx: Dict[tuple, tuple] = {}  # prompt -> cross-attention K / V^T (a few entries: cond/uncond ranks share a process in tests)
         self._load(state_dict)
 
     # ---------------------------------------------------------------- weights
@@ -160,8 +170,9 @@ class WanDiT:
     def _context(self, text: torch.Tensor):
         """text [B,L,4096] -> per-block cross-attention K [B*L,d] and V^T [d,B*Lp]; cached while `text` is unchanged."""
         key = (text.data_ptr(), tuple(text.shape), text._version)
-        if self._ctx_key == key:
-            return self._ctx
+        hit = self._ctx.get(key)
+        if hit is not None:
+            return hit
         cfg = self.cfg
         B, Lt, _ = text.shape
         d = cfg.dim
@@ -178,30 +189,42 @@ class WanDiT:
                 ops.gemm(b["wv2"], c[bi * Lt:(bi + 1) * Lt], b["bv2"], out=vt[:, bi * Lp: bi * Lp + Lt], bias_row=True)
             ks.append(k)
             vts.append(vt)
-        self._ctx_key, self._ctx = key, (ks, vts, Lt, Lp)
-        return self._ctx
+        if len(self._ctx) >= 4:
+            self._ctx.pop(next(iter(self._ctx)))
+        self._ctx[key] = (ks, vts, Lt, Lp)
+        return self._ctx[key]
 
     # ---------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
-                return_dict: bool = False, num_layers: Optional[int] = None):
+                return_dict: bool = False, num_layers: Optional[int] = None, sp=None):
+        """`sp` (wan/seqpar.py group) shards the latent tokens over sp.world ranks: every rank passes the SAME full
+        `hidden_states` and gets the full prediction back; only N/P token rows are computed locally."""
         cfg = self.cfg
         B, C, Fr, Hh, Ww = hidden_states.shape
         pt, ph, pw = cfg.patch_size
         ppf, pph, ppw = Fr // pt, Hh // ph, Ww // pw
         N, d, H, hd = ppf * pph * ppw, cfg.dim, cfg.num_attention_heads, cfg.attention_head_dim
-        M = B * N
-        ws = self._ws.get((B, N))
+        P, rk = (1, 0) if sp is None else (sp.world, sp.rank)
+        if N % P or (P > 1 and (N // P) % 8):
+            raise ValueError(f"{N} tokens do not split into {P} shards of a multiple of 8 rows")
+        Nl = N // P  # local tokens [rk*Nl, (rk+1)*Nl) of every batch item
+        wkey = (B, N, P, rk, threading.get_ident())  # per thread: virtual ranks (seqpar.ThreadWorld) must not share buffers
+        ws = self._ws.get(wkey)
         if ws is None:
-            ws = self._ws[(B, N)] = _Workspace(B, N, cfg, self.device)
+            ws = self._ws[wkey] = _Workspace(B, Nl, N, P, cfg, self.device)
         rope = self._rope.get((ppf, pph, ppw))
         if rope is None:
             rope = self._rope[(ppf, pph, ppw)] = rope_table(cfg, ppf, pph, ppw, self.device)
+        rope = rope[rk * Nl:(rk + 1) * Nl]
         ks, vts, Lt, Lp = self._context(encoder_hidden_states)
 
         # patchify: Conv3d(k=s=(1,2,2)) == GEMM over (c,pt,ph,pw)-major patches
         x5 = hidden_states.to(bf16).view(B, C, ppf, pt, pph, ph, ppw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
-        ws.tok.view(B, ppf, pph, ppw, C, pt, ph, pw).copy_(x5)
+        if P == 1:
+            ws.tok.view(B, ppf, pph, ppw, C, pt, ph, pw).copy_(x5)
+        else:
+            ws.tok.view(B, Nl, -1).copy_(x5.reshape(B, N, -1)[:, rk * Nl:(rk + 1) * Nl])
         x = ops.gemm(ws.tok, self.patch_w, self.patch_b, out=ws.x)
 
         # time conditioning (M = B rows: latency-only work)
@@ -213,36 +236,60 @@ class WanDiT:
         mod = (self.sst[:, None] + tproj.float().view(1, B, 6, d)).contiguous()  # [L,B,6,d] f32
 
         nl = cfg.num_layers if num_layers is None else num_layers
-        q, k = ws.qk[:, :d], ws.qk[:, d:]
-        vbs = ws.vt.shape[1] // B
+        Ml = B * Nl
+        if P == 1:
+            q, k = ws.qk[:, :d], ws.qk[:, d:]
+            vbs = ws.vt.shape[1] // B
+        else:
+            kl, vtl = ws.pack[:Ml * d].view(Ml, d), ws.pack[Ml * d:].view(d, Ml)
+            vt_full = ws.vt[:, :B * N]
         for li in range(nl):
             b, m = self.blocks[li], mod[li]
             # --- self attention
-            ops.layernorm(x, out=ws.n, scale=m[:, 1], shift=m[:, 0], rows_per_batch=N, eps=cfg.eps)
-            ops.gemm(ws.n, b["wqk"], b["bqk"], out=ws.qk)
-            for bi in range(B):
-                ops.gemm(b["wv"], ws.n[bi * N:(bi + 1) * N], b["bv"], out=ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True)
-            ops.rmsnorm_rope(q, b["nq"], out=q, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps)
-            ops.rmsnorm_rope(k, b["nk"], out=k, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps)
-            ops.attention(q, k, ws.vt, ws.ao, B=B, H=H, Nq=N, Nk=N, D=hd, q_batch_stride=N * 2 * d,
-                          k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d)
-            ops.gemm(ws.ao, b["wo"], b["bo"], out=x, residual=x, scale=m[:, 2], rows_per_batch=N)
+            ops.layernorm(x, out=ws.n, scale=m[:, 1], shift=m[:, 0], rows_per_batch=Nl, eps=cfg.eps)
+            if P == 1:
+                ops.gemm(ws.n, b["wqk"], b["bqk"], out=ws.qk)
+                for bi in range(B):
+                    ops.gemm(b["wv"], ws.n[bi * N:(bi + 1) * N], b["bv"], out=ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True)
+                ops.rmsnorm_rope(q, b["nq"], out=q, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps)
+                ops.rmsnorm_rope(k, b["nk"], out=k, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps)
+                ops.attention(q, k, ws.vt, ws.ao, B=B, H=H, Nq=N, Nk=N, D=hd, q_batch_stride=N * 2 * d,
+                              k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d)
+            else:
+                # K and V^T of the local tokens first, so their all-gather rides under the Q projection
+                ops.gemm(ws.n, b["wqk"][d:], b["bqk"][d:], out=kl)
+                ops.rmsnorm_rope(kl, b["nk"], out=kl, rope=rope, head_dim=hd, tokens_per_batch=Nl, eps=cfg.eps)
+                ops.gemm(b["wv"], ws.n, b["bv"], out=vtl, bias_row=True)
+                pending = sp.all_gather(ws.gbuf, ws.pack)
+                ops.gemm(ws.n, b["wqk"][:d], b["bqk"][:d], out=ws.q)
+                ops.rmsnorm_rope(ws.q, b["nq"], out=ws.q, rope=rope, head_dim=hd, tokens_per_batch=Nl, eps=cfg.eps)
+                pending.wait()
+                ws.kfull.view(B, P, Nl, d).copy_(ws.gbuf[:, :Ml * d].view(P, B, Nl, d).permute(1, 0, 2, 3))
+                vt_full.view(d, B, P, Nl).copy_(ws.gbuf[:, Ml * d:].view(P, d, B, Nl).permute(1, 2, 0, 3))
+                ops.attention(ws.q, ws.kfull, ws.vt, ws.ao, B=B, H=H, Nq=Nl, Nk=N, D=hd, q_batch_stride=Nl * d,
+                              k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=Nl * d)
+            ops.gemm(ws.ao, b["wo"], b["bo"], out=x, residual=x, scale=m[:, 2], rows_per_batch=Nl)
             # --- cross attention
             ops.layernorm(x, out=ws.n, weight=b["n2w"], bias=b["n2b"], eps=cfg.eps)
             ops.gemm(ws.n, b["wq2"], b["bq2"], out=ws.q2)
             ops.rmsnorm_rope(ws.q2, b["nq2"], out=ws.q2, eps=cfg.eps)
-            ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=N, Nk=Lt, D=hd, q_batch_stride=N * d,
-                          k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=N * d)
+            ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lt, D=hd, q_batch_stride=Nl * d,
+                          k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d)
             ops.gemm(ws.ao, b["wo2"], b["bo2"], out=x, residual=x)
             # --- feed forward
-            ops.layernorm(x, out=ws.n, scale=m[:, 4], shift=m[:, 3], rows_per_batch=N, eps=cfg.eps)
+            ops.layernorm(x, out=ws.n, scale=m[:, 4], shift=m[:, 3], rows_per_batch=Nl, eps=cfg.eps)
             ops.gemm(ws.n, b["w1"], b["b1"], out=ws.h, act=L.ACT_GELU_TANH)
-            ops.gemm(ws.h, b["w2"], b["b2"], out=x, residual=x, scale=m[:, 5], rows_per_batch=N)
+            ops.gemm(ws.h, b["w2"], b["b2"], out=x, residual=x, scale=m[:, 5], rows_per_batch=Nl)
 
         om = (self.out_sst[None] + temb.float()[:, None]).contiguous()  # [B,2,d]
-        ops.layernorm(x, out=ws.n, scale=om[:, 1], shift=om[:, 0], rows_per_batch=N, eps=cfg.eps)
+        ops.layernorm(x, out=ws.n, scale=om[:, 1], shift=om[:, 0], rows_per_batch=Nl, eps=cfg.eps)
         ops.gemm(ws.n, self.po_w, self.po_b, out=ws.out)
-        o = ws.out.view(B, ppf, pph, ppw, pt, ph, pw, cfg.out_channels).permute(0, 7, 1, 4, 2, 5, 3, 6)
+        if P == 1:
+            tokens = ws.out
+        else:
+            sp.all_gather(ws.ogather, ws.out).wait()
+            tokens = ws.ogather.view(P, B, Nl, -1).permute(1, 0, 2, 3)
+        o = tokens.reshape(B, ppf, pph, ppw, pt, ph, pw, cfg.out_channels).permute(0, 7, 1, 4, 2, 5, 3, 6)
         o = o.reshape(B, cfg.out_channels, Fr, Hh, Ww)
         return o if return_dict else (o,)
 

@@ -30,7 +30,9 @@ class WanT2VPipeline:
     vae_scale_factor_spatial = 8
 
     def __init__(self, transformer, scheduler: UniPCMultistepScheduler, vae=None,
-                 text_encoder: Optional[Callable[[List[str], int], torch.Tensor]] = None, device="cuda"):
+                 text_encoder: Optional[Callable[[List[str], int], torch.Tensor]] = None, device="cuda", plan=None):
+        """`plan` (wan/seqpar.py DenoisePlan) spreads ONE scene over several ranks; None = everything on this GPU."""
+        self.plan = plan
         self.transformer = transformer
         self.scheduler = scheduler
         self.vae = vae
@@ -71,15 +73,24 @@ class WanT2VPipeline:
         if tuple(latents.shape) != shape:
             raise ValueError(f"latents shape {tuple(latents.shape)} != {shape}")
         self.scheduler.set_timesteps(num_inference_steps, device=self.device)
-        if do_cfg:
+        cfgp = self.plan.cfg if (self.plan is not None and do_cfg) else None
+        sp = self.plan.sp if self.plan is not None else None
+        if cfgp is not None:  # CFG-parallel: rank 0 of the pair runs the conditional branch, rank 1 the unconditional
+            text = (prompt_embeds if cfgp.rank == 0 else negative_prompt_embeds).to(self.device).contiguous()
+        elif do_cfg:
             text = torch.cat([prompt_embeds, negative_prompt_embeds], 0).to(self.device).contiguous()
         else:
             text = prompt_embeds.to(self.device).contiguous()
         nb = text.shape[0]
+        pair = torch.empty((2,) + shape, device=self.device, dtype=torch.bfloat16) if cfgp is not None else None
         for i, t in enumerate(self.scheduler.timesteps):
             x_in = latents.to(torch.bfloat16).expand(nb, -1, -1, -1, -1)
-            noise = self.transformer(x_in, t.expand(nb), text, return_dict=False)[0]
-            if do_cfg:
+            noise = self.transformer(x_in, t.expand(nb), text, return_dict=False, sp=sp)[0]
+            if cfgp is not None:
+                cfgp.all_gather(pair, noise.contiguous()).wait()
+                n_c, n_u = pair[0], pair[1]
+                noise = n_u + guidance_scale * (n_c - n_u)
+            elif do_cfg:
                 n_c, n_u = noise[0:1], noise[1:2]
                 noise = n_u + guidance_scale * (n_c - n_u)  # bf16 arithmetic, as the reference pipeline
             latents = self.scheduler.step(noise, t, latents, return_dict=False)[0]
