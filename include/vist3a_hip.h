@@ -21,6 +21,7 @@ extern "C" {
 #define V3A_ERR_ARG (-1)
 #define V3A_ERR_SHAPE (-2)
 #define V3A_ERR_LAUNCH (-3)
+#define V3A_ERR_WORKSPACE (-4)
 
 int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 2) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
@@ -201,6 +202,52 @@ int v3a_gaussian_adapter(const float* pts, const float* feats, int ldf, long U, 
 int v3a_linear_f32(const float* x, const float* w, const float* bias, float* y, const float* residual, const float* gamma,
                    int M, int N, int K, int ldx, int ldy, int ldr, int act, void* stream);
 int v3a_attention_small_f32(const float* qkv, float* out, int S, int H, int hd, float scale, void* stream);
+
+/* ---- 3D-Gaussian rasteriser: gsplat==1.4.0 `rasterization(..., render_mode="RGB+D", packed=False,
+ * near_plane=1e-10, radius_clip=0.1, covars=..., rasterize_mode="classic")`, ONE camera per call, as driven by
+ * third_party_model/anysplat/src/model/decoder/decoder_splatting_cuda.py:96-125.  All pointers are device pointers unless
+ * noted.  Stage 1 = fully_fused_projection + spherical_harmonics (colours only for radii > 0, clamp_min(c + 0.5, 0)). */
+typedef struct {
+  const float* means;    /* [U,3] world */
+  const float* covars;   /* [U,3,3] world covariance, row-major; the upper triangle is used */
+  const float* sh;       /* harmonics */
+  int sh_layout;         /* 0: [U,K,3] (gsplat argument layout), 1: [U,3,K] (Gaussians.harmonics layout, types.py) */
+  int sh_k;              /* K coefficients stored per channel (25) */
+  int sh_degree;         /* 0..4 evaluated */
+  const float* viewmat;  /* [4,4] world->camera, row-major */
+  const float* campos;   /* [3] camera centre in world = inverse(viewmat)[:3,3] */
+  const float* K;        /* [3,3] pixel intrinsics */
+  long U;
+  int width, height;
+  float near_plane, far_plane, radius_clip, eps2d;
+  int* radii;            /* out [U]: 3-sigma pixel radius, 0 = culled */
+  float* means2d;        /* out [U,2] */
+  float* depths;         /* out [U] camera z */
+  float* conics;         /* out [U,3] inverse 2D covariance (a,b,c) */
+  float* colors;         /* out [U,4] rgb + depth */
+} v3a_gs_project_args;
+int v3a_gs_project(const v3a_gs_project_args* a, void* stream);
+
+/* Stage 2 = isect_tiles + radix sort by (tile, depth bits) + isect_offset_encode + rasterize_to_pixels (16x16 tiles).
+ * Synchronises the stream once (4-byte read-back of the intersection count that sizes the sort, like gsplat's .item()).
+ * Returns V3A_ERR_WORKSPACE (-4) when *n_isect > max_isect: call again with a workspace sized for *n_isect. */
+typedef struct {
+  const int* radii; const float* means2d; const float* depths; const float* conics; const float* colors;
+  const float* opacities;   /* [U] */
+  const float* background;  /* [3] RGB or NULL (the depth channel's background is 0) */
+  long U;
+  int width, height;
+  int clamp_rgb;            /* 1: clamp RGB to [0,1] (decoder_splatting_cuda.py:117) */
+  float* out_color;         /* [H,W,3] */
+  float* out_depth;         /* [H,W]  sum(vis_i * z_i) */
+  float* out_alpha;         /* [H,W]  1 - T */
+  void* workspace; long workspace_bytes; long max_isect;
+  long* n_isect;            /* HOST pointer: intersections found */
+  unsigned int* tile_offsets_out;  /* optional [ntiles+1] */
+  unsigned int* flatten_ids_out;   /* optional [max_isect]: Gaussian ids in composite order */
+} v3a_gs_rasterize_args;
+long v3a_gs_rasterize_workspace_bytes(long U, int width, int height, long max_isect);
+int v3a_gs_rasterize(const v3a_gs_rasterize_args* a, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
 """Text -> 3DGS inference CLI — drop-in for /root/reference/inference_t23d.py (same flags, same output layout
-`<output_dir>/<prompt[:100] sans '/'>/{prompt.txt, gaussians.ply}`; gs.mp4 / depth.mp4 need the rasteriser: SURVEY.md §8f rank 1).
+`<output_dir>/<prompt[:100] sans '/'>/{prompt.txt, gaussians.ply, gs.avi, depth.avi}` — the videos are Motion-JPEG AVI instead of
+the reference's mp4: no H.264 encoder exists in this image).
 
     python -m torch.distributed.run --nproc_per_node=K --master-addr 127.0.0.1 inference_t23d.py --checkpoint_path ... \
         --transformer_lora_path ... --input_texts_path prompts.txt
@@ -20,6 +21,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 from vist3a_amd.models.loading import load_stitching_model  # noqa: E402
+from vist3a_amd.misc.image_io import save_interpolated_video  # noqa: E402
 from vist3a_amd.t23d import Text23DGS, synthetic_text_embeddings  # noqa: E402
 from vist3a_amd.utils.argument import inference_vist3a_argument  # noqa: E402
 from vist3a_amd.utils.dist_util import setup_dist, shard_prompts  # noqa: E402
@@ -78,6 +80,9 @@ def main(args):
         os.makedirs(save, exist_ok=args.overwrite)  # the reference raises when the directory exists (inference_t23d.py:126)
         (save / "prompt.txt").write_text(prompt)
         g = out.gaussians
+        if not args.no_video:  # orbit video through the predicted context poses (reference :144-154)
+            save_interpolated_video(out.pred_context_pose["extrinsic"], out.pred_context_pose["intrinsic"], 1, args.feedforward_resolution,
+                                    args.feedforward_resolution, g, str(save), stitched.stitched_3d_model.decoder)
         export_ply(g.means[0], g.scales[0], g.rotations[0], g.harmonics[0], g.opacities[0], save / "gaussians.ply", save_sh_dc_only=True)
         print(f"[rank {rank}] {save}: {g.means.shape[1]} gaussians", flush=True)
     if world > 1:

@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define V3A_ERR_ARG (-1)
 #define V3A_ERR_SHAPE (-2)
 #define V3A_ERR_LAUNCH (-3)
+#define V3A_ERR_WORKSPACE (-4)
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))

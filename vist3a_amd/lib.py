@@ -11,7 +11,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libvist3a_hip.so"
 
 V3A_OK = 0
-ERRORS = {-1: "V3A_ERR_ARG", -2: "V3A_ERR_SHAPE", -3: "V3A_ERR_LAUNCH"}
+ERRORS = {-1: "V3A_ERR_ARG", -2: "V3A_ERR_SHAPE", -3: "V3A_ERR_LAUNCH", -4: "V3A_ERR_WORKSPACE"}
 
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2, 3, 4
 GEMM_BIAS_ROW = 1 << 0
@@ -49,6 +49,30 @@ class ConvArgs(C.Structure):
         ("residual2", C.c_void_p), ("ldr2", C.c_int), ("res_row_mod", C.c_int),
         ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
     ]
+
+
+class GsProjectArgs(C.Structure):
+    _fields_ = [
+        ("means", C.c_void_p), ("covars", C.c_void_p), ("sh", C.c_void_p),
+        ("sh_layout", C.c_int), ("sh_k", C.c_int), ("sh_degree", C.c_int),
+        ("viewmat", C.c_void_p), ("campos", C.c_void_p), ("K", C.c_void_p),
+        ("U", C.c_long), ("width", C.c_int), ("height", C.c_int),
+        ("near_plane", C.c_float), ("far_plane", C.c_float), ("radius_clip", C.c_float), ("eps2d", C.c_float),
+        ("radii", C.c_void_p), ("means2d", C.c_void_p), ("depths", C.c_void_p), ("conics", C.c_void_p), ("colors", C.c_void_p),
+    ]
+
+
+class GsRasterizeArgs(C.Structure):
+    _fields_ = [
+        ("radii", C.c_void_p), ("means2d", C.c_void_p), ("depths", C.c_void_p), ("conics", C.c_void_p), ("colors", C.c_void_p),
+        ("opacities", C.c_void_p), ("background", C.c_void_p),
+        ("U", C.c_long), ("width", C.c_int), ("height", C.c_int), ("clamp_rgb", C.c_int),
+        ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_long), ("max_isect", C.c_long),
+        ("n_isect", C.POINTER(C.c_long)),
+        ("tile_offsets_out", C.c_void_p), ("flatten_ids_out", C.c_void_p),
+    ]
+
 
 
 class AttnArgs(C.Structure):
@@ -117,6 +141,9 @@ SYMBOLS = {
     "v3a_gaussian_adapter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_float] + [C.c_void_p] * 8),
     "v3a_linear_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
     "v3a_attention_small_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "v3a_gs_project": (C.c_int, [C.POINTER(GsProjectArgs), C.c_void_p]),
+    "v3a_gs_rasterize_workspace_bytes": (C.c_long, [C.c_long, C.c_int, C.c_int, C.c_long]),
+    "v3a_gs_rasterize": (C.c_int, [C.POINTER(GsRasterizeArgs), C.c_void_p]),
     "v3a_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
 }
 

@@ -59,8 +59,16 @@ class AnySplatStitched(torch.nn.Module):
         self.encoder.cfg = SimpleNamespace(voxelize=cfg.voxelize, voxel_size=cfg.voxel_size, pred_head_type="depth", render_conf=False,
                                            opacity_conf=False, conf_threshold=0.1)
         self.encoder.raw_gs_dim = 1 + 7 + 3 * (cfg.sh_degree + 1) ** 2
-        self.decoder = None
+        self._decoder = None
         self.grad_checkpointing = False
+
+    @property
+    def decoder(self):
+        """Rasteriser (config/model/decoder/splatting_cuda.yaml: white background), built on first use."""
+        if self._decoder is None:
+            from .decoder_splatting import DecoderSplattingCUDA
+            self._decoder = DecoderSplattingCUDA(background_color=(1.0, 1.0, 1.0), make_scale_invariant=False, device=self._device)
+        return self._decoder
 
     def load_lora(self, lora_sd: Dict[str, torch.Tensor], alpha: float, r: int) -> int:
         from ..recon.weights import merge_lora

@@ -38,6 +38,7 @@ def inference_vist3a_argument() -> argparse.ArgumentParser:
     g.add_argument("--synthetic_text", action="store_true", help="seeded synthetic text embeddings (weights-free smoke runs)")
     g.add_argument("--scene_parallel", action="store_true",
                    help="all ranks cooperate on each prompt (CFG-parallel x sequence-parallel DiT over RCCL) instead of striding prompts")
+    g.add_argument("--no_video", action="store_true", help="skip the interpolated orbit render (gs.avi / depth.avi)")
     g.add_argument("--overwrite", action="store_true", help="reuse an existing output directory (the reference raises)")
     return p
 
