@@ -147,6 +147,19 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    # the step after the path, reported beside the metric, never inside it: orbit render of the last scene
+    render_ms = None
+    if rank == 0:
+        from vist3a_amd.misc.image_io import interpolate_camera_path
+        ex, ix = interpolate_camera_path(out.pred_context_pose["extrinsic"], out.pred_context_pose["intrinsic"], 1, 10)
+        dec = model.stitched_decoder.stitched_3d_model.decoder
+        ones = torch.ones(1, ex.shape[1], device=dev)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            tr = time.perf_counter()
+            dec.forward(out.gaussians, ex, ix.float(), ones * 0.1, ones * 100, (448, 448))
+            torch.cuda.synchronize()
+            render_ms = (time.perf_counter() - tr) * 1e3
     if rank == 0:
         ps = probe.summary()
         ach = ps["flops_per_launch"] / (ps["avg_ms"] * 1e-3) / 1e12 if ps["launches"] else 0.0
@@ -163,6 +176,7 @@ def main():
                        "denoise_steps": a.denoise_steps, "views": a.num_frames, "dit_tokens": N, "gaussians_last_scene": U,
                        "stage_ms_last_scene": {"denoise": round(stage.denoise_ms, 1), "vae_decode+resize": round(stage.vae_ms, 1),
                                                "stitch+recon": round(stage.recon_ms, 1)},
+                       "orbit_render_ms_132_cameras_448 (untimed extra)": round(render_ms, 1),
                        "dit_model_tflops_per_s": round(2 * a.denoise_steps * fwd_flops / (stage.denoise_ms * 1e-3) / 1e12, 1)},
             "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<{lib.load().v3a_gemm_tile_name(dom_tile).decode()}> (bf16 MFMA 32x32x16)",
                          "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),

@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 2) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 3) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -204,9 +204,10 @@ int v3a_linear_f32(const float* x, const float* w, const float* bias, float* y, 
 int v3a_attention_small_f32(const float* qkv, float* out, int S, int H, int hd, float scale, void* stream);
 
 /* ---- 3D-Gaussian rasteriser: gsplat==1.4.0 `rasterization(..., render_mode="RGB+D", packed=False,
- * near_plane=1e-10, radius_clip=0.1, covars=..., rasterize_mode="classic")`, ONE camera per call, as driven by
- * third_party_model/anysplat/src/model/decoder/decoder_splatting_cuda.py:96-125.  All pointers are device pointers unless
- * noted.  Stage 1 = fully_fused_projection + spherical_harmonics (colours only for radii > 0, clamp_min(c + 0.5, 0)). */
+ * near_plane=1e-10, radius_clip=0.1, covars=..., rasterize_mode="classic")` as driven by
+ * third_party_model/anysplat/src/model/decoder/decoder_splatting_cuda.py:96-125.  The reference passes one camera per call;
+ * here a call takes C cameras (gsplat's own leading C dimension): per camera the arithmetic is identical, the batch is what
+ * fills 256 CUs.  Per-camera arrays are camera-major ([C,U,...], [C,H,W,...]).  All pointers are device pointers unless noted.  Stage 1 = fully_fused_projection + spherical_harmonics (colours only for radii > 0, clamp_min(c + 0.5, 0)). */
 typedef struct {
   const float* means;    /* [U,3] world */
   const float* covars;   /* [U,3,3] world covariance, row-major; the upper triangle is used */
@@ -214,17 +215,18 @@ typedef struct {
   int sh_layout;         /* 0: [U,K,3] (gsplat argument layout), 1: [U,3,K] (Gaussians.harmonics layout, types.py) */
   int sh_k;              /* K coefficients stored per channel (25) */
   int sh_degree;         /* 0..4 evaluated */
-  const float* viewmat;  /* [4,4] world->camera, row-major */
-  const float* campos;   /* [3] camera centre in world = inverse(viewmat)[:3,3] */
-  const float* K;        /* [3,3] pixel intrinsics */
+  const float* viewmat;  /* [C,4,4] world->camera, row-major */
+  const float* campos;   /* [C,3] camera centre in world = inverse(viewmat)[:3,3] */
+  const float* K;        /* [C,3,3] pixel intrinsics */
   long U;
+  int C;
   int width, height;
   float near_plane, far_plane, radius_clip, eps2d;
-  int* radii;            /* out [U]: 3-sigma pixel radius, 0 = culled */
-  float* means2d;        /* out [U,2] */
-  float* depths;         /* out [U] camera z */
-  float* conics;         /* out [U,3] inverse 2D covariance (a,b,c) */
-  float* colors;         /* out [U,4] rgb + depth */
+  int* radii;            /* out [C,U]: 3-sigma pixel radius, 0 = culled */
+  float* means2d;        /* out [C,U,2] */
+  float* depths;         /* out [C,U] camera z */
+  float* conics;         /* out [C,U,3] inverse 2D covariance (a,b,c) */
+  float* colors;         /* out [C,U,4] rgb + depth */
 } v3a_gs_project_args;
 int v3a_gs_project(const v3a_gs_project_args* a, void* stream);
 
@@ -233,20 +235,21 @@ int v3a_gs_project(const v3a_gs_project_args* a, void* stream);
  * Returns V3A_ERR_WORKSPACE (-4) when *n_isect > max_isect: call again with a workspace sized for *n_isect. */
 typedef struct {
   const int* radii; const float* means2d; const float* depths; const float* conics; const float* colors;
-  const float* opacities;   /* [U] */
+  const float* opacities;   /* [U] (shared by the cameras) */
   const float* background;  /* [3] RGB or NULL (the depth channel's background is 0) */
   long U;
+  int C;
   int width, height;
   int clamp_rgb;            /* 1: clamp RGB to [0,1] (decoder_splatting_cuda.py:117) */
-  float* out_color;         /* [H,W,3] */
-  float* out_depth;         /* [H,W]  sum(vis_i * z_i) */
-  float* out_alpha;         /* [H,W]  1 - T */
+  float* out_color;         /* [C,H,W,3] */
+  float* out_depth;         /* [C,H,W]  sum(vis_i * z_i) */
+  float* out_alpha;         /* [C,H,W]  1 - T */
   void* workspace; long workspace_bytes; long max_isect;
   long* n_isect;            /* HOST pointer: intersections found */
-  unsigned int* tile_offsets_out;  /* optional [ntiles+1] */
-  unsigned int* flatten_ids_out;   /* optional [max_isect]: Gaussian ids in composite order */
+  unsigned int* tile_offsets_out;  /* optional [C*ntiles+1] */
+  unsigned int* flatten_ids_out;   /* optional [max_isect]: entry ids c*U+g in composite order */
 } v3a_gs_rasterize_args;
-long v3a_gs_rasterize_workspace_bytes(long U, int width, int height, long max_isect);
+long v3a_gs_rasterize_workspace_bytes(long U, int C, int width, int height, long max_isect);
 int v3a_gs_rasterize(const v3a_gs_rasterize_args* a, void* stream);
 
 #ifdef __cplusplus

@@ -133,12 +133,41 @@ def test_workspace_grows_when_intersections_exceed_capacity(hip_lib):
     view, K = _camera(256, 256, 200.0)
     pr = _project_gpu(ops, means, cov, sh, view, K, 256, 256)
     ws = ops.GsWorkspace()
-    ws.get(2000, 256, 256, 1)
+    ws.get(2000, 1, 256, 256, 1)
     ws.cap = 64  # pretend the scratch was sized for a tiny scene
     a = ops.gs_rasterize(pr, op.cuda(), 256, 256, workspace=ws)
     assert a["n_isect"] > 64 and ws.cap >= a["n_isect"]
     b = ops.gs_rasterize(pr, op.cuda(), 256, 256)
     assert torch.equal(a["color"], b["color"]) and torch.equal(a["alpha"], b["alpha"])
+
+
+def test_camera_batch_equals_single_camera_calls(hip_lib):
+    """C cameras in one launch (camera-major keys) == C one-camera launches, bit for bit; composite ids are c*U + g."""
+    from vist3a_amd import ops
+    U, W, H = 3000, 100, 70
+    means, cov, sh, op = _scene(U, 11, scale=0.2)
+    cams = [_camera(W, H, 65.0 + 5 * i, yaw=0.1 * i - 0.1, t=(0.05 * i, 0.0, 0.1 * i)) for i in range(3)]
+    view = torch.stack([c[0] for c in cams]).cuda()
+    K = torch.stack([c[1] for c in cams]).cuda()
+    campos = torch.stack([torch.linalg.inv(c[0])[:3, 3] for c in cams]).contiguous().cuda()
+    m, c, s_, o = means.cuda(), cov.cuda(), sh.cuda(), op.cuda()
+    bg = torch.tensor([1.0, 0.5, 0.0], device="cuda")
+    prb = ops.gs_project(m, c, s_, view, campos, K, W, H)
+    outb = ops.gs_rasterize(prb, o, W, H, background=bg, return_order=True)
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    tot = 0
+    for j in range(3):
+        pr1 = ops.gs_project(m, c, s_, view[j].contiguous(), campos[j].contiguous(), K[j].contiguous(), W, H)
+        for k in pr1:
+            assert torch.equal(pr1[k], prb[k][j])
+        o1 = ops.gs_rasterize(pr1, o, W, H, background=bg, return_order=True)
+        for k in ("color", "depth", "alpha"):
+            assert torch.equal(o1[k], outb[k][j])
+        lo, hi = int(outb["tile_offsets"][j * ntiles]), int(outb["tile_offsets"][(j + 1) * ntiles])
+        assert hi - lo == o1["n_isect"]
+        assert torch.equal(outb["flatten_ids"][lo:hi] - j * U, o1["flatten_ids"])
+        tot += o1["n_isect"]
+    assert tot == outb["n_isect"]
 
 
 def test_decoder_end_to_end_vs_oracle(hip_lib):
@@ -152,7 +181,7 @@ def test_decoder_end_to_end_vs_oracle(hip_lib):
     views = [_camera(W, H, 80.0, yaw=a, t=(0.1 * i, 0.0, 0.2))[0] for i, a in enumerate((0.0, 0.15, -0.2))]
     c2w = torch.stack([torch.linalg.inv(v) for v in views])[None]
     Kn = torch.tensor([[80.0 / W, 0, 0.5], [0, 88.0 / H, 0.5], [0, 0, 1.0]])[None, None].repeat(1, 3, 1, 1)
-    dec = DecoderSplattingCUDA(background_color=(1.0, 1.0, 1.0))
+    dec = DecoderSplattingCUDA(background_color=(1.0, 1.0, 1.0), camera_batch=2)  # 3 views -> batches of 2 + 1
     out = dec.forward(g, c2w.cuda(), Kn.cuda(), torch.full((1, 3), 0.1).cuda(), torch.full((1, 3), 100.0).cuda(), (H, W))
     assert out.color.shape == (1, 3, 3, H, W) and out.depth.shape == (1, 3, H, W) and out.alpha.shape == (1, 3, H, W)
     for j in range(3):

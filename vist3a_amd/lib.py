@@ -56,7 +56,7 @@ class GsProjectArgs(C.Structure):
         ("means", C.c_void_p), ("covars", C.c_void_p), ("sh", C.c_void_p),
         ("sh_layout", C.c_int), ("sh_k", C.c_int), ("sh_degree", C.c_int),
         ("viewmat", C.c_void_p), ("campos", C.c_void_p), ("K", C.c_void_p),
-        ("U", C.c_long), ("width", C.c_int), ("height", C.c_int),
+        ("U", C.c_long), ("C", C.c_int), ("width", C.c_int), ("height", C.c_int),
         ("near_plane", C.c_float), ("far_plane", C.c_float), ("radius_clip", C.c_float), ("eps2d", C.c_float),
         ("radii", C.c_void_p), ("means2d", C.c_void_p), ("depths", C.c_void_p), ("conics", C.c_void_p), ("colors", C.c_void_p),
     ]
@@ -66,7 +66,7 @@ class GsRasterizeArgs(C.Structure):
     _fields_ = [
         ("radii", C.c_void_p), ("means2d", C.c_void_p), ("depths", C.c_void_p), ("conics", C.c_void_p), ("colors", C.c_void_p),
         ("opacities", C.c_void_p), ("background", C.c_void_p),
-        ("U", C.c_long), ("width", C.c_int), ("height", C.c_int), ("clamp_rgb", C.c_int),
+        ("U", C.c_long), ("C", C.c_int), ("width", C.c_int), ("height", C.c_int), ("clamp_rgb", C.c_int),
         ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("out_alpha", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_long), ("max_isect", C.c_long),
         ("n_isect", C.POINTER(C.c_long)),
@@ -142,7 +142,7 @@ SYMBOLS = {
     "v3a_linear_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
     "v3a_attention_small_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "v3a_gs_project": (C.c_int, [C.POINTER(GsProjectArgs), C.c_void_p]),
-    "v3a_gs_rasterize_workspace_bytes": (C.c_long, [C.c_long, C.c_int, C.c_int, C.c_long]),
+    "v3a_gs_rasterize_workspace_bytes": (C.c_long, [C.c_long, C.c_int, C.c_int, C.c_int, C.c_long]),
     "v3a_gs_rasterize": (C.c_int, [C.POINTER(GsRasterizeArgs), C.c_void_p]),
     "v3a_softmax_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
 }

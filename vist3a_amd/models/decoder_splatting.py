@@ -27,12 +27,14 @@ class DecoderOutput:
 
 
 class DecoderSplattingCUDA:
-    def __init__(self, background_color: Sequence[float] = (1.0, 1.0, 1.0), make_scale_invariant: bool = False, device="cuda"):
+    def __init__(self, background_color: Sequence[float] = (1.0, 1.0, 1.0), make_scale_invariant: bool = False, device="cuda",
+                 camera_batch: int = 12):
+        self.camera_batch = camera_batch  # cameras per rasteriser launch (scratch = camera_batch * U * 44 B + sort buffers)
         self.make_scale_invariant = make_scale_invariant
         self.device = torch.device(device)
         self.background_color = torch.tensor(list(background_color), dtype=torch.float32, device=self.device)
         self._ws = ops.GsWorkspace()
-        self.last_n_isect = []  # per rendered camera, for reporting
+        self.last_n_isect = []  # per rendered camera batch, for reporting
 
     def rendering_fn(self, gaussians: Gaussians, extrinsics, intrinsics, near, far, image_shape, depth_mode=None,
                      cam_rot_delta=None, cam_trans_delta=None, cov_ignore: bool = False) -> DecoderOutput:
@@ -57,17 +59,18 @@ class DecoderSplattingCUDA:
             K[:, 1] = K[:, 1] * H
             w2c_d, cam_d, K_d = w2c.contiguous().to(dev), c2w[:, :3, 3].contiguous().to(dev), K.contiguous().to(dev)
             ci, di, ai = [], [], []
-            for j in range(V):
-                pr = ops.gs_project(means, cov, sh, w2c_d[j], cam_d[j], K_d[j], W, H, sh_degree=sh_degree, sh_layout=1,
-                                    near_plane=1e-10, far_plane=1e10, radius_clip=0.1, eps2d=0.3)
+            for j0 in range(0, V, self.camera_batch):  # the reference renders one camera per call; same arithmetic, batched
+                sl = slice(j0, min(j0 + self.camera_batch, V))
+                pr = ops.gs_project(means, cov, sh, w2c_d[sl].contiguous(), cam_d[sl].contiguous(), K_d[sl].contiguous(), W, H,
+                                    sh_degree=sh_degree, sh_layout=1, near_plane=1e-10, far_plane=1e10, radius_clip=0.1, eps2d=0.3)
                 r = ops.gs_rasterize(pr, op, W, H, background=self.background_color, clamp_rgb=True, workspace=self._ws)
                 self.last_n_isect.append(r["n_isect"])
-                ci.append(r["color"].permute(2, 0, 1))
+                ci.append(r["color"].permute(0, 3, 1, 2))
                 di.append(r["depth"])
                 ai.append(r["alpha"])
-            imgs.append(torch.stack(ci))
-            depths.append(torch.stack(di).squeeze())
-            alphas.append(torch.stack(ai).squeeze())
+            imgs.append(torch.cat(ci))
+            depths.append(torch.cat(di).squeeze())
+            alphas.append(torch.cat(ai).squeeze())
         return DecoderOutput(torch.stack(imgs), torch.stack(depths), torch.stack(alphas), lod_rendering=None)
 
     def forward(self, gaussians: Gaussians, extrinsics, intrinsics, near, far, image_shape, depth_mode=None, cam_rot_delta=None,

@@ -428,32 +428,38 @@ def attention_small_f32(qkv: torch.Tensor, H: int) -> torch.Tensor:
 def gs_project(means: torch.Tensor, covars: torch.Tensor, sh: torch.Tensor, viewmat: torch.Tensor, campos: torch.Tensor,
                K: torch.Tensor, width: int, height: int, *, sh_degree: int = 4, sh_layout: int = 1, near_plane: float = 1e-10,
                far_plane: float = 1e10, radius_clip: float = 0.1, eps2d: float = 0.3):
-    """fully_fused_projection + SH colours for one camera.  sh: [U,3,K] (sh_layout=1, Gaussians.harmonics) or [U,K,3] (0)."""
+    """fully_fused_projection + SH colours for C cameras at once (viewmat [C,4,4], campos [C,3], K [C,3,3] -> outputs [C,U,...])
+    or one camera (viewmat [4,4] -> outputs [U,...]).  sh: [U,3,K] (sh_layout=1, Gaussians.harmonics) or [U,K,3] (0)."""
     for t, n in ((means, "means"), (covars, "covars"), (sh, "sh"), (viewmat, "viewmat"), (campos, "campos"), (K, "K")):
         if t.dtype != f32 or not t.is_cuda or not t.is_contiguous():
             raise ValueError(f"{n}: contiguous fp32 device tensor required")
+    single = viewmat.dim() == 2
+    Cn = 1 if single else viewmat.shape[0]
+    if campos.numel() != 3 * Cn or K.numel() != 9 * Cn or viewmat.numel() != 16 * Cn:
+        raise ValueError("viewmat / campos / K disagree on the number of cameras")
     U, dev = means.shape[0], means.device
     sh_k = sh.shape[2] if sh_layout == 1 else sh.shape[1]
-    radii = torch.empty(U, device=dev, dtype=torch.int32)
-    e = lambda *s: torch.empty(*s, device=dev, dtype=f32)
+    lead = () if single else (Cn,)
+    radii = torch.empty(*lead, U, device=dev, dtype=torch.int32)
+    e = lambda *s: torch.empty(*lead, *s, device=dev, dtype=f32)
     m2, dep, con, col = e(U, 2), e(U), e(U, 3), e(U, 4)
-    a = L.GsProjectArgs(_ptr(means), _ptr(covars), _ptr(sh), sh_layout, sh_k, sh_degree, _ptr(viewmat), _ptr(campos), _ptr(K), U,
+    a = L.GsProjectArgs(_ptr(means), _ptr(covars), _ptr(sh), sh_layout, sh_k, sh_degree, _ptr(viewmat), _ptr(campos), _ptr(K), U, Cn,
                         width, height, near_plane, far_plane, radius_clip, eps2d, _ptr(radii), _ptr(m2), _ptr(dep), _ptr(con), _ptr(col))
     L.check(L.load().v3a_gs_project(C.byref(a), _stream()), "v3a_gs_project")
     return dict(radii=radii, means2d=m2, depths=dep, conics=con, colors=col)
 
 
 class GsWorkspace:
-    """Grow-only scratch for v3a_gs_rasterize, shared by the cameras of one video."""
+    """Grow-only scratch for v3a_gs_rasterize, shared by the camera batches of one video."""
 
     def __init__(self):
         self.buf, self.cap, self.key = None, 0, None
 
-    def get(self, U, width, height, need):
-        key = (U, width, height)
+    def get(self, U, Cn, width, height, need):
+        key = (U, Cn, width, height)
         if self.buf is None or self.key != key or need > self.cap:
             self.cap = max(int(need * 1.25), 1 << 20)
-            nbytes = L.load().v3a_gs_rasterize_workspace_bytes(U, width, height, self.cap)
+            nbytes = L.load().v3a_gs_rasterize_workspace_bytes(U, Cn, width, height, self.cap)
             if nbytes < 0:
                 L.check(int(nbytes), "v3a_gs_rasterize_workspace_bytes")
             self.buf, self.key = None, key
@@ -463,25 +469,29 @@ class GsWorkspace:
 
 def gs_rasterize(proj: dict, opacities: torch.Tensor, width: int, height: int, *, background: Optional[torch.Tensor] = None,
                  clamp_rgb: bool = True, workspace: Optional[GsWorkspace] = None, return_order: bool = False):
-    """isect_tiles + sort + rasterize_to_pixels for one camera -> dict(color [H,W,3], depth [H,W], alpha [H,W], n_isect)."""
+    """isect_tiles + sort + rasterize_to_pixels for the cameras of `proj` -> dict(color [C,H,W,3], depth [C,H,W], alpha [C,H,W],
+    n_isect); without the C axis when `proj` came from a single-camera gs_project call."""
     U, dev = opacities.shape[0], opacities.device
     if opacities.dtype != f32 or not opacities.is_contiguous():
         raise ValueError("opacities: contiguous fp32 [U] required")
     if U == 0:
         raise ValueError("no Gaussians to draw")
+    single = proj["radii"].dim() == 1
+    Cn = 1 if single else proj["radii"].shape[0]
+    lead = () if single else (Cn,)
     wsp = workspace or GsWorkspace()
-    color = torch.empty(height, width, 3, device=dev, dtype=f32)
-    depth = torch.empty(height, width, device=dev, dtype=f32)
-    alpha = torch.empty(height, width, device=dev, dtype=f32)
+    color = torch.empty(*lead, height, width, 3, device=dev, dtype=f32)
+    depth = torch.empty(*lead, height, width, device=dev, dtype=f32)
+    alpha = torch.empty(*lead, height, width, device=dev, dtype=f32)
     ntiles = ((width + 15) // 16) * ((height + 15) // 16)
     n_host = C.c_long(0)
     need = max(wsp.cap, 1)
     for _ in range(2):
-        buf = wsp.get(U, width, height, need)
-        offs = torch.empty(ntiles + 1, device=dev, dtype=torch.int32) if return_order else None
+        buf = wsp.get(U, Cn, width, height, need)
+        offs = torch.empty(Cn * ntiles + 1, device=dev, dtype=torch.int32) if return_order else None
         ids = torch.empty(wsp.cap, device=dev, dtype=torch.int32) if return_order else None
         a = L.GsRasterizeArgs(_ptr(proj["radii"]), _ptr(proj["means2d"]), _ptr(proj["depths"]), _ptr(proj["conics"]), _ptr(proj["colors"]),
-                              _ptr(opacities), _ptr(background) if background is not None else None, U, width, height, int(clamp_rgb),
+                              _ptr(opacities), _ptr(background) if background is not None else None, U, Cn, width, height, int(clamp_rgb),
                               _ptr(color), _ptr(depth), _ptr(alpha), _ptr(buf), buf.numel(), wsp.cap, C.pointer(n_host),
                               _ptr(offs) if return_order else None, _ptr(ids) if return_order else None)
         rc = L.load().v3a_gs_rasterize(C.byref(a), _stream())
