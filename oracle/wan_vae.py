@@ -1,12 +1,15 @@
-"""ORACLE (test infrastructure).  CPU fp32 restatement of the Wan-2.1 VAE *decoder* (SURVEY.md §8a rows V1-V7).
+"""ORACLE (test infrastructure).  CPU fp32 restatement of the Wan-2.1 VAE *decoder*  and, for the
+image-conditioned entry `StitchVAE3D.forward`, of the *encoder*.
 
 Follows /root/reference/utils/wan_utils.py (the vendored twin of diffusers' AutoencoderKLWan that
 `pipe.vae.decode` runs at /root/reference/inference_t23d.py:114):
     WanCausalConv3d :96-147   WanRMS_norm :150-184   WanResample :202-330   WanResidualBlock :333-425
     WanAttentionBlock :428-475   WanMidBlock :478-531   WanUpBlock :667-749   WanDecoder3d :752-901
     AutoencoderKLWan._decode :1078-1117
-PARITY PINNED: tests/golden/vae_decode_tiny.safetensors is produced by running the reference module itself
-(tests/golden/make_golden.py, stub-imported in the build container) on weights from `make_weights` below.
+    WanEncoder3d :534-662   AutoencoderKLWan._encode :1021-1047 (+ diffusers DiagonalGaussianDistribution)
+PARITY PINNED: tests/golden/vae_decode_tiny.safetensors / vae_encode_tiny.safetensors are produced by running the reference
+module itself (tests/golden/make_golden.py, stub-imported in the build container) on weights from `make_weights` /
+`make_encoder_weights` below.
 
 The reference decodes one latent frame per call and threads a cache of the last two input frames through every
 causal conv.  That is arithmetically a causal convolution over the whole frame sequence (two zero frames in
@@ -158,4 +161,100 @@ def make_weights(cfg: WanVAEConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
     conv(d + "conv_out", 3, plan[-1][1], (3, 3, 3))
     sd[d + "conv_out.weight"] *= 0.25  # keep most of the output inside the final clamp(-1, 1)
     sd[d + "conv_out.bias"] *= 0.25
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------- encoder
+def encoder_plan(cfg: WanVAEConfig):
+    """Flat `down_blocks` list of WanEncoder3d.__init__ (:571-590): [("res", in, out) | ("down", dim, mode)]."""
+    dims = [cfg.base_dim * u for u in [1] + cfg.dim_mult]
+    plan = []
+    for i, (i_d, o_d) in enumerate(zip(dims[:-1], dims[1:])):
+        cur = i_d
+        for _ in range(cfg.num_res_blocks):
+            plan.append(("res", cur, o_d))
+            cur = o_d
+        if i != len(cfg.dim_mult) - 1:
+            plan.append(("down", o_d, "downsample3d" if cfg.temperal_downsample[i] else "downsample2d"))
+    return dims, plan
+
+
+def downsample(sd, p, x, mode):
+    """WanResample downsample2d / downsample3d (:232-243, 303-329) in whole-clip form.  The reference feeds chunks of
+    1, 4, 4, ... frames: the first chunk bypasses time_conv (its output is only cached), every later chunk runs the
+    stride-2 (3,1,1) conv over [last cached frame, chunk] — i.e. out[0] = y[0], out[k] = conv(y[2k-2], y[2k-1], y[2k])."""
+    B, C, T, H, W = x.shape
+    y = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    y = F.conv2d(F.pad(y, (0, 1, 0, 1)), sd[p + "resample.1.weight"], sd[p + "resample.1.bias"], stride=2)
+    y = y.view(B, T, C, y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
+    if mode == "downsample3d" and T > 1:
+        rest = F.conv3d(y, sd[p + "time_conv.weight"], sd[p + "time_conv.bias"], stride=(2, 1, 1))
+        y = torch.cat([y[:, :, :1], rest], 2)
+    return y
+
+
+def encode(sd: Dict[str, torch.Tensor], cfg: WanVAEConfig, x: torch.Tensor) -> torch.Tensor:
+    """AutoencoderKLWan._encode: video [B,3,1+4n,H,W] in [-1,1] -> posterior parameters [B,2*z_dim,1+n,H/8,W/8]
+    (mean | logvar).  Every causal conv over chunk+cache equals a causal conv over the whole clip (zero frames in front)."""
+    sd = {k: v.float() for k, v in sd.items()}
+    e = "encoder."
+    x = causal_conv3d(x.float(), sd[e + "conv_in.weight"], sd[e + "conv_in.bias"], (1, 1, 1))
+    _, plan = encoder_plan(cfg)
+    for i, item in enumerate(plan):
+        p = e + f"down_blocks.{i}."
+        x = res_block(sd, p, x) if item[0] == "res" else downsample(sd, p, x, item[2])
+    x = res_block(sd, e + "mid_block.resnets.0.", x)
+    x = attn_block(sd, e + "mid_block.attentions.0.", x)
+    x = res_block(sd, e + "mid_block.resnets.1.", x)
+    x = F.silu(rms_norm(x, sd[e + "norm_out.gamma"]))
+    x = causal_conv3d(x, sd[e + "conv_out.weight"], sd[e + "conv_out.bias"], (1, 1, 1))
+    return causal_conv3d(x, sd["quant_conv.weight"], sd["quant_conv.bias"], (0, 0, 0))
+
+
+def posterior_sample(params: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """diffusers DiagonalGaussianDistribution(params).sample(): mean + exp(0.5*clamp(logvar,-30,20)) * noise."""
+    mean, logvar = torch.chunk(params, 2, dim=1)
+    return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
+
+
+def make_encoder_weights(cfg: WanVAEConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded encoder(+quant_conv) weights under the reference's state-dict names."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, o, i, k):
+        sd[name + ".weight"] = torch.randn(o, i, *k, generator=g) / math.sqrt(i * math.prod(k))
+        sd[name + ".bias"] = torch.randn(o, generator=g) * 0.05
+
+    def gamma(name, c, nd):
+        sd[name + ".gamma"] = 1 + 0.1 * torch.randn(c, *([1] * nd), generator=g)
+
+    def res(p, i, o):
+        gamma(p + "norm1", i, 3)
+        conv(p + "conv1", o, i, (3, 3, 3))
+        gamma(p + "norm2", o, 3)
+        conv(p + "conv2", o, o, (3, 3, 3))
+        if i != o:
+            conv(p + "conv_shortcut", o, i, (1, 1, 1))
+
+    e = "encoder."
+    dims, plan = encoder_plan(cfg)
+    conv(e + "conv_in", dims[0], 3, (3, 3, 3))
+    for i, item in enumerate(plan):
+        p = e + f"down_blocks.{i}."
+        if item[0] == "res":
+            res(p, item[1], item[2])
+        else:
+            conv(p + "resample.1", item[1], item[1], (3, 3))
+            if item[2] == "downsample3d":
+                conv(p + "time_conv", item[1], item[1], (3, 1, 1))
+    d = dims[-1]
+    res(e + "mid_block.resnets.0.", d, d)
+    gamma(e + "mid_block.attentions.0.norm", d, 2)
+    conv(e + "mid_block.attentions.0.to_qkv", 3 * d, d, (1, 1))
+    conv(e + "mid_block.attentions.0.proj", d, d, (1, 1))
+    res(e + "mid_block.resnets.1.", d, d)
+    gamma(e + "norm_out", d, 3)
+    conv(e + "conv_out", 2 * cfg.z_dim, d, (3, 3, 3))
+    conv("quant_conv", 2 * cfg.z_dim, 2 * cfg.z_dim, (1, 1, 1))
     return sd

@@ -51,6 +51,29 @@ def vae_decode_tiny():
     _save("vae_decode_tiny", {"z": z, "out": ref})
 
 
+def vae_encode_tiny():
+    """AutoencoderKLWan(base_dim=16)._encode on x[1,3,9,64,64] -> [1,32,3,8,8] (chunks of 1,4,4 frames, cached reference path)."""
+    import utils.wan_utils as W
+    from oracle import wan_vae as OV
+    cfg = OV.WanVAEConfig(base_dim=16)
+    sd = OV.make_encoder_weights(cfg, seed=12)
+    vae = W.AutoencoderKLWan(base_dim=16)
+    missing = vae.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if k.startswith(("encoder.", "quant_conv"))]
+    assert not missing.unexpected_keys
+    x = torch.randn(1, 3, 9, 64, 64, generator=torch.Generator().manual_seed(22)).clamp(-1, 1)
+    with torch.no_grad():
+        ref = vae._encode(x)
+        mine = OV.encode(sd, cfg, x)
+        # a second, odd-shaped clip (5 frames = chunks 1+4, non-square) keeps the chunk/cache equivalence honest
+        x2 = torch.randn(1, 3, 5, 32, 48, generator=torch.Generator().manual_seed(23)).clamp(-1, 1)
+        ref2, mine2 = vae._encode(x2), OV.encode(sd, cfg, x2)
+    err, err2 = (ref - mine).abs().max().item(), (ref2 - mine2).abs().max().item()
+    print(f"vae_encode_tiny: oracle vs reference max abs err {err:.2e} / {err2:.2e}; out {tuple(ref.shape)} {tuple(ref2.shape)}")
+    assert err < 2e-5 and err2 < 2e-5
+    _save("vae_encode_tiny", {"x": x, "out": ref, "x2": x2, "out2": ref2})
+
+
 def stitch_tiny():
     """stitched_model.py:92-107 trilinear T-upsample + stitching_layer_builder.py ConvSpec.build (replicate pad)."""
     from models.stitching_layer_builder import parse_conv_spec
@@ -201,7 +224,7 @@ def voxel_collide():
                             "keys": keys, "inverse": inv.to(torch.int32), "counts": cnt.to(torch.int32)})
 
 
-GENERATORS = {f.__name__: f for f in [vae_decode_tiny, stitch_tiny, recon_tiny, voxel_collide]}
+GENERATORS = {f.__name__: f for f in [vae_decode_tiny, vae_encode_tiny, stitch_tiny, recon_tiny, voxel_collide]}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)

@@ -56,6 +56,40 @@ def test_forward_with_latent_matches_oracle(hip_lib):
     assert out2.gaussians.means.shape[1] == S * H * H
 
 
+def test_image_conditioned_forward_equals_encode_then_forward_with_latent(hip_lib):
+    """StitchVAE3D.forward (stitched_model.py:139-163): VAE-encode the views, sample the posterior, forward_with_latent."""
+    from oracle import wan_vae as OV
+    from vist3a_amd.models.anysplat_stitched import AnySplatWeights
+    from vist3a_amd.models.stitched_model import StitchVAE3D
+    from vist3a_amd.models.stitching_layer_builder import parse_conv_spec
+    from vist3a_amd.recon.engine import ReconCfg
+    from vist3a_amd.wan.vae import WanVAEConfig, WanVAEDecoder
+    vcfg = OV.WanVAEConfig(base_dim=16)
+    vsd = dict(OV.make_weights(vcfg, seed=5))
+    vsd.update(OV.make_encoder_weights(vcfg, seed=6))
+    vae = WanVAEDecoder(WanVAEConfig(base_dim=16), vsd)
+    sd = R.make_recon_weights(R.ReconCfg(**RECON_TINY), seed=7)
+    model = StitchVAE3D(vae, AnySplatWeights(dict(sd), ReconCfg(**RECON_TINY)), "cuda", "enc_blocks_2",
+                        parse_conv_spec("conv3d_k5x3x3_o64_s1x2x2_p2x1x1"), resolution=32)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        model.stitching_layer.weight.copy_(torch.randn(64, 16, 5, 3, 3, generator=g) * 0.08)
+    S, H = 5, 28
+    images = (torch.rand(1, 3, S, 32, 32, generator=g) * 2 - 1).cuda()   # 5 views @ 32^2 -> latent [1,16,2,4,4]
+    ff = (torch.rand(1, 3, S, H, H, generator=g) * 2 - 1).cuda()
+    out = model.forward(images, ff, train=False, generator=torch.Generator().manual_seed(1))
+    lat, none = model.vae_encoder_forward(images, decode=False, generator=torch.Generator().manual_seed(1))
+    assert none is None and lat.shape == (1, 16, 2, 4, 4)
+    ref = model.forward_with_latent(lat, ff, train=False)
+    assert torch.equal(out.last_pred_pose_enc, ref.last_pred_pose_enc) and torch.equal(out.gaussians.means, ref.gaussians.means)
+    # the latent really is the oracle's posterior sample of the oracle's encoding (bf16 conv stack: 2e-2)
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(1))
+    want = OV.posterior_sample(OV.encode(vsd, vcfg, images.cpu()), noise)
+    assert _rel(lat, want) < 2e-2
+    lat2, dec = model.vae_encoder_forward(images, decode=True, generator=torch.Generator().manual_seed(1))
+    assert dec.shape == (1, 3, S, 32, 32)
+
+
 def test_scene_pipeline_properties_reduced(hip_lib):
     """Text23DGS.generate end to end at reduced DiT/recon width but production 512^2/448^2 geometry: determinism, finiteness,
     size-independent invariants (unit quaternions, symmetric PSD covariances, opacity in (0,1), scale clamp, sorted voxel keys)."""

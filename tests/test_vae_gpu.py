@@ -44,3 +44,59 @@ def test_decode_matches_oracle_shapes(hip_lib, T, hw):
     r = _rel(out, ref)
     print("vae rel", T, hw, r)
     assert r < 2e-2, r
+
+
+ENC_GOLD = Path(__file__).parent / "golden" / "vae_encode_tiny.safetensors"
+
+
+def test_encode_matches_reference_golden(hip_lib):
+    """HIP whole-clip encoder vs the reference's chunked/cached `_encode` output (posterior mean | logvar).
+    Tolerance 2e-2 relative L2: ~30 bf16 conv layers, bf16 activations between layers (as the reference under autocast)."""
+    from vist3a_amd.wan.vae import WanVAEConfig, WanVAEEncoder
+    g = load_file(str(ENC_GOLD))
+    sd = OV.make_encoder_weights(OV.WanVAEConfig(base_dim=16), seed=12)
+    enc = WanVAEEncoder(WanVAEConfig(base_dim=16), sd)
+    for xk, ok in (("x", "out"), ("x2", "out2")):
+        out = enc.encode_params(g[xk].cuda())
+        torch.cuda.synchronize()
+        assert out.shape == g[ok].shape and out.dtype == torch.float32
+        r = _rel(out, g[ok])
+        print("vae encode golden rel", xk, r)
+        assert r < 2e-2, r
+
+
+@pytest.mark.parametrize("T,h,w", [(1, 32, 32), (5, 48, 32), (13, 32, 32)])
+def test_encode_matches_oracle_shapes(hip_lib, T, h, w):
+    from vist3a_amd.wan.vae import WanVAEConfig, WanVAEEncoder
+    cfg = OV.WanVAEConfig(base_dim=16)
+    sd = OV.make_encoder_weights(cfg, seed=6)
+    enc = WanVAEEncoder(WanVAEConfig(base_dim=16), sd)
+    x = torch.randn(1, 3, T, h, w, generator=torch.Generator().manual_seed(T)).clamp(-1, 1)
+    ref = OV.encode(sd, cfg, x)
+    out = enc.encode_params(x.cuda())
+    assert out.shape == ref.shape == (1, 32, 1 + (T - 1) // 4, h // 8, w // 8)
+    r = _rel(out, ref)
+    print("vae encode rel", T, h, w, r)
+    assert r < 2e-2, r
+
+
+def test_encode_surface_and_roundtrip_shapes(hip_lib):
+    """AutoencoderKLWan surface: encode(x).latent_dist.sample()/mode(); decoder-only state dicts refuse to encode."""
+    from vist3a_amd.wan.vae import WanVAEConfig, WanVAEDecoder
+    cfg = OV.WanVAEConfig(base_dim=16)
+    sd = dict(OV.make_weights(cfg, seed=5))
+    dec_only = WanVAEDecoder(WanVAEConfig(base_dim=16), sd)
+    x = torch.randn(1, 3, 5, 32, 32, generator=torch.Generator().manual_seed(0)).clamp(-1, 1).cuda()
+    with pytest.raises(RuntimeError):
+        dec_only.encode(x)
+    sd.update(OV.make_encoder_weights(cfg, seed=6))
+    vae = WanVAEDecoder(WanVAEConfig(base_dim=16), sd)
+    dist = vae.encode(x).latent_dist
+    assert dist.mean.shape == (1, 16, 2, 4, 4)
+    z1 = dist.sample(torch.Generator().manual_seed(3))
+    z2 = dist.sample(torch.Generator().manual_seed(3))
+    assert torch.equal(z1, z2) and not torch.equal(z1, dist.mode())
+    noise = torch.randn(dist.mean.shape, generator=torch.Generator().manual_seed(3))
+    assert torch.allclose(z1.cpu(), OV.posterior_sample(dist.parameters.cpu(), noise), atol=1e-6)
+    video = vae.decode(dist.mode())[0]
+    assert video.shape == (1, 3, 5, 32, 32)

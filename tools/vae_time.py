@@ -20,3 +20,17 @@ for _ in range(n):
 e1.record(); torch.cuda.synchronize()
 print(json.dumps(dict(vae_decode_ms=e0.elapsed_time(e1) / n, shape=list(o.shape), finite=bool(torch.isfinite(o.float()).all()),
                       peak_mem_GB=torch.cuda.max_memory_allocated() / 2**30)))
+
+# encoder (StitchVAE3D.forward path): 13 views @512^2 -> latent [1,32,4,64,64]
+from vist3a_amd.wan.vae import WanVAEEncoder
+from oracle.wan_vae import make_encoder_weights
+enc = WanVAEEncoder(WanVAEConfig(), make_encoder_weights(OC(), seed=1))
+x = (torch.rand(1, 3, 1 + 4 * (Tl - 1), 512, 512, device="cuda") * 2 - 1)
+for _ in range(2):
+    p = enc.encode_params(x)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(n):
+    p = enc.encode_params(x)
+e1.record(); torch.cuda.synchronize()
+print(json.dumps(dict(vae_encode_ms=e0.elapsed_time(e1) / n, shape=list(p.shape), finite=bool(torch.isfinite(p).all()))))

@@ -53,9 +53,20 @@ class StitchVAE3D(torch.nn.Module):
             self._packed, self._packed_key = ops.ConvWeight(wd, None if b is None else b.detach(), device=self.device), key
         return self._packed
 
-    def forward(self, images, feedforward_image, train=False):
-        raise NotImplementedError("the image-conditioned path needs the Wan VAE *encoder* (SURVEY.md §8f rank 4: next row); "
-                                  "text->3DGS inference enters through forward_with_latent")
+    @torch.no_grad()
+    def vae_encoder_forward(self, images: torch.Tensor, decode: bool = False, generator: Optional[torch.Generator] = None):
+        """stitched_model.py:122-137: latents = vae.encode(images).latent_dist.sample() (images [1,3,T,H,W] in [-1,1])."""
+        latents = self.diffusion_vae.encode(images).latent_dist.sample(generator)
+        feedforward_image = self.diffusion_vae.decode(latents)[0] if decode else None
+        return latents, feedforward_image
+
+    @torch.no_grad()
+    def forward(self, images, feedforward_image, train=False, generator: Optional[torch.Generator] = None):
+        """Image-conditioned entry (stitched_model.py:139-163; the NVS evaluation path): encode the views with the Wan VAE, sample
+        the posterior (`generator` makes the draw reproducible; the reference uses the global CUDA RNG), then exactly
+        `forward_with_latent`.  The reference never decodes here (decode=False), so `feedforward_image` is used as given."""
+        latent, _ = self.vae_encoder_forward(images, decode=False, generator=generator)
+        return self.forward_with_latent(latent, feedforward_image, train=train)
 
     @torch.no_grad()
     def forward_with_latent(self, latent: torch.Tensor, feedforward_image: torch.Tensor, train: bool = False, image_cl: Optional[torch.Tensor] = None):

@@ -14,7 +14,7 @@ MI355X-first restructuring (identical arithmetic, different schedule):
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
@@ -62,6 +62,46 @@ class _Res:
         return ops.conv(n, self.c2, pad=(2, 1, 1), residual=h)
 
 
+class _Attn:
+    """WanAttentionBlock (wan_utils.py:428-475): one C-wide head per frame — QK^T GEMM -> row softmax -> PV GEMM."""
+
+    def __init__(self, sd, a, dev):
+        g = lambda k: sd[k].reshape(-1).to(device=dev, dtype=f32).contiguous()
+        C = sd[a + "proj.weight"].shape[0]
+        self.C = C
+        self.g = g(a + "norm.gamma")
+        wqkv = sd[a + "to_qkv.weight"].reshape(3 * C, C)
+        bqkv = sd[a + "to_qkv.bias"]
+        self.wqk = wqkv[: 2 * C].to(device=dev, dtype=bf16).contiguous()
+        self.bqk = bqkv[: 2 * C].to(device=dev, dtype=f32).contiguous()
+        self.wv = wqkv[2 * C:].to(device=dev, dtype=bf16).contiguous()
+        self.bv = bqkv[2 * C:].to(device=dev, dtype=f32).contiguous()
+        self.wproj = sd[a + "proj.weight"].reshape(C, C).to(device=dev, dtype=bf16).contiguous()
+        self.bproj = sd[a + "proj.bias"].to(device=dev, dtype=f32).contiguous()
+
+    def __call__(self, x):
+        T, H, W, C = x.shape
+        HW = H * W
+        x2 = x.view(T * HW, C)
+        n = ops.rownorm_act(x, self.g, mode=1).view(T * HW, C)
+        qk = ops.gemm(n, self.wqk, self.bqk)
+        if HW % 8:
+            raise ValueError(f"mid-block attention needs H*W % 8 == 0 (got {H}x{W})")
+        HWp = (HW + 63) // 64 * 64  # the PV GEMM's K dimension: zero probabilities x zero V^T columns in the pad
+        o = torch.empty(T * HW, C, device=x.device, dtype=bf16)
+        s = torch.empty(HW, HW, device=x.device, dtype=f32)
+        pm = torch.zeros(HW, HWp, device=x.device, dtype=bf16)
+        vt = torch.zeros(C, HWp, device=x.device, dtype=bf16)
+        for t in range(T):
+            sl = slice(t * HW, (t + 1) * HW)
+            ops.gemm(self.wv, n[sl], self.bv, out=vt[:, :HW], bias_row=True)
+            ops.gemm(qk[sl, :C], qk[sl, C:], out=s, out_f32=True)
+            ops.softmax_rows(s, C ** -0.5, out=pm[:, :HW])
+            ops.gemm(pm, vt, out=o[sl])
+        y = ops.gemm(o, self.wproj, self.bproj, residual=x2)
+        return y.view(T, H, W, C)
+
+
 class WanVAEDecoder:
     """decode(z) with the AutoencoderKLWan.decode signature subset the reference uses."""
 
@@ -76,18 +116,7 @@ class WanVAEDecoder:
         self.conv_in = cw(d + "conv_in")
         self.mid0 = _Res(sd, d + "mid_block.resnets.0.", dev)
         self.mid1 = _Res(sd, d + "mid_block.resnets.1.", dev)
-        a = d + "mid_block.attentions.0."
-        C = sd[a + "proj.weight"].shape[0]
-        self.attn_C = C
-        self.attn_g = g(a + "norm.gamma")
-        wqkv = sd[a + "to_qkv.weight"].reshape(3 * C, C)
-        bqkv = sd[a + "to_qkv.bias"]
-        self.wqk = wqkv[: 2 * C].to(device=dev, dtype=bf16).contiguous()
-        self.bqk = bqkv[: 2 * C].to(device=dev, dtype=f32).contiguous()
-        self.wv = wqkv[2 * C:].to(device=dev, dtype=bf16).contiguous()
-        self.bv = bqkv[2 * C:].to(device=dev, dtype=f32).contiguous()
-        self.wproj = sd[a + "proj.weight"].reshape(C, C).to(device=dev, dtype=bf16).contiguous()
-        self.bproj = sd[a + "proj.bias"].to(device=dev, dtype=f32).contiguous()
+        self.attn = _Attn(sd, d + "mid_block.attentions.0.", dev)
         _, plan = cfg.decoder_plan()
         self.ups = []
         for i, (_, o_d, mode) in enumerate(plan):
@@ -100,25 +129,14 @@ class WanVAEDecoder:
             self.ups.append((res, mode, rs, tc, o_d))
         self.g_out = g(d + "norm_out.gamma")
         self.conv_out = cw(d + "conv_out")
+        # the full AutoencoderKLWan checkpoint also carries the encoder (needed only by StitchVAE3D.forward)
+        self.encoder = WanVAEEncoder(cfg, sd, device=dev) if "encoder.conv_in.weight" in sd else None
 
-    def _attn(self, x):
-        T, H, W, C = x.shape
-        HW = H * W
-        x2 = x.view(T * HW, C)
-        n = ops.rownorm_act(x, self.attn_g, mode=1).view(T * HW, C)
-        qk = ops.gemm(n, self.wqk, self.bqk)
-        o = torch.empty(T * HW, C, device=x.device, dtype=bf16)
-        s = torch.empty(HW, HW, device=x.device, dtype=f32)
-        pm = torch.empty(HW, HW, device=x.device, dtype=bf16)
-        vt = torch.empty(C, HW, device=x.device, dtype=bf16)
-        for t in range(T):  # one 384-wide head per frame: QK^T GEMM -> row softmax -> PV GEMM
-            sl = slice(t * HW, (t + 1) * HW)
-            ops.gemm(self.wv, n[sl], self.bv, out=vt, bias_row=True)
-            ops.gemm(qk[sl, :C], qk[sl, C:], out=s, out_f32=True)
-            ops.softmax_rows(s, C ** -0.5, out=pm)
-            ops.gemm(pm, vt, out=o[sl])
-        y = ops.gemm(o, self.wproj, self.bproj, residual=x2)
-        return y.view(T, H, W, C)
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """AutoencoderKLWan.encode surface: video [1,3,1+4n,H,W] in [-1,1] -> .latent_dist (sample / mode)."""
+        if self.encoder is None:
+            raise RuntimeError("this VAE was built from a decoder-only state dict: no `encoder.*` / `quant_conv.*` weights to encode with")
+        return self.encoder.encode(x, return_dict=return_dict)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = False):
@@ -137,7 +155,7 @@ class WanVAEDecoder:
         x = ops.conv(x, self.pq)
         x = ops.conv(x, self.conv_in, pad=(2, 1, 1))
         x = self.mid0(x)
-        x = self._attn(x)
+        x = self.attn(x)
         x = self.mid1(x)
         for res, mode, rs, tc, C in self.ups:
             for r in res:
@@ -156,3 +174,91 @@ class WanVAEDecoder:
         n = ops.rownorm_act(x, self.g_out, mode=1, act=L.ACT_SILU)
         y = ops.conv(n, self.conv_out, pad=(2, 1, 1))  # [T,H,W,8] (3 real channels, 5 zero)
         return y.clamp_(-1.0, 1.0)
+
+
+class LatentDist:
+    """The slice of diffusers' DiagonalGaussianDistribution the reference touches (`.sample()`, `.mode()`)."""
+
+    def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
+        self.mean, lv = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(lv, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        gdev = generator.device if generator is not None else self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=gdev, dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * noise
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
+class EncoderOutputKL:
+    def __init__(self, latent_dist: LatentDist):
+        self.latent_dist = latent_dist
+
+
+class WanVAEEncoder:
+    """`AutoencoderKLWan.encode` for the image-conditioned entry `StitchVAE3D.forward` (SURVEY.md §8f rank 4;
+    /root/reference/utils/wan_utils.py:534-662, 1021-1076).  Same restructuring as the decoder: the reference encodes chunks of
+    1,4,4,... frames through per-conv caches; here the whole clip goes through each layer once — causal convs see zero frames in
+    front, `downsample3d` keeps its first-chunk quirk (frame 0 bypasses the stride-2 time_conv: out[0] = y[0],
+    out[k] = conv(y[2k-2], y[2k-1], y[2k]))."""
+
+    def __init__(self, cfg: WanVAEConfig, state_dict: Dict[str, torch.Tensor], device="cuda"):
+        L.load()
+        self.cfg, self.device = cfg, torch.device(device)
+        sd, dev = state_dict, self.device
+        cw = lambda n: ops.ConvWeight(sd[n + ".weight"], sd[n + ".bias"], device=dev)
+        e = "encoder."
+        self.conv_in = cw(e + "conv_in")
+        dims = [cfg.base_dim * u for u in [1] + cfg.dim_mult]
+        self.blocks = []
+        idx = 0
+        for i in range(len(cfg.dim_mult)):
+            for _ in range(cfg.num_res_blocks):
+                self.blocks.append(("res", _Res(sd, e + f"down_blocks.{idx}.", dev)))
+                idx += 1
+            if i != len(cfg.dim_mult) - 1:
+                p = e + f"down_blocks.{idx}."
+                tc = cw(p + "time_conv") if cfg.temperal_downsample[i] else None
+                self.blocks.append(("down", (cw(p + "resample.1"), tc)))
+                idx += 1
+        self.mid0 = _Res(sd, e + "mid_block.resnets.0.", dev)
+        self.attn = _Attn(sd, e + "mid_block.attentions.0.", dev)
+        self.mid1 = _Res(sd, e + "mid_block.resnets.1.", dev)
+        self.g_out = sd[e + "norm_out.gamma"].reshape(-1).to(device=dev, dtype=f32).contiguous()
+        self.conv_out = cw(e + "conv_out")
+        self.quant = cw("quant_conv")
+        self.z2 = sd["quant_conv.weight"].shape[0]
+        self.in_pad = self.conv_in.CinP
+
+    @torch.no_grad()
+    def encode_params(self, x: torch.Tensor) -> torch.Tensor:
+        """video [1,3,1+4n,H,W] in [-1,1] -> posterior parameters [1,2*z_dim,1+n,H/8,W/8] fp32 (mean | logvar)."""
+        if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != 3:
+            raise ValueError("expected x [1, 3, T, H, W]")
+        T, H, W = x.shape[2:]
+        h = torch.zeros(T, H, W, self.in_pad, device=self.device, dtype=bf16)
+        h[..., :3] = x[0].permute(1, 2, 3, 0).to(device=self.device, dtype=bf16)
+        h = ops.conv(h, self.conv_in, pad=(2, 1, 1))
+        for kind, blk in self.blocks:
+            if kind == "res":
+                h = blk(h)
+                continue
+            rs, tc = blk
+            t, hh, ww = h.shape[:3]
+            h = ops.conv(h, rs, stride=(1, 2, 2), pad=(0, 0, 0), out_size=(t, hh // 2, ww // 2))  # ZeroPad2d((0,1,0,1)) + stride 2
+            if tc is not None and t > 1:
+                rest = ops.conv(h, tc, stride=(2, 1, 1), pad=(0, 0, 0))
+                h = torch.cat([h[:1], rest], 0)
+        h = self.mid1(self.attn(self.mid0(h)))
+        n = ops.rownorm_act(h, self.g_out, mode=1, act=L.ACT_SILU)
+        h = ops.conv(n, self.conv_out, pad=(2, 1, 1))
+        h = ops.conv(h, self.quant, out_f32=True)
+        return h[..., : self.z2].permute(3, 0, 1, 2).unsqueeze(0).contiguous()
+
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        dist = LatentDist(self.encode_params(x))
+        return EncoderOutputKL(dist) if return_dict else (dist,)
