@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 3) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 4) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -119,6 +119,9 @@ typedef struct {
   int B, H, Nq, Nk, D;
   float scale;                                              /* softmax scale, normally D^-0.5 */
   int kv_period, kv_valid;  /* kv_period > 0: key k participates only if (k % kv_period) < kv_valid (per-frame row padding) */
+  const float* rel_bias;    /* optional (D = 64 only): additive bias by relative position, fp32 [H][rel_bias_stride], entry
+                             * (key - query + rel_bias_center) is added to scale*q.k — T5/UMT5 relative attention bias */
+  int rel_bias_stride, rel_bias_center;
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 
@@ -137,6 +140,7 @@ typedef struct {
   int x_is_f32, y_is_f32;
   int in_row_group, in_row_skip, in_row_off;    /* group > 0: logical row m reads x row m + (m/group)*skip + off */
   int out_row_group, out_row_skip, out_row_off; /* same for the output (gather/scatter of per-frame token blocks) */
+  int rms;                                      /* 1: RMS norm, no mean subtraction (T5LayerNorm of the UMT5 text encoder) */
 } v3a_layernorm_args;
 int v3a_layernorm(const v3a_layernorm_args* args, void* stream);
 

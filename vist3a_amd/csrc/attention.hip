@@ -3,6 +3,7 @@
 //   DiT   : diffusers==0.33.1 WanAttnProcessor2_0 (self-attn N=4096/6144 hd=128, cross-attn Nk=512)
 //   recon : /root/reference/third_party_model/anysplat/src/model/encoder/vggt/layers/attention.py:64-69
 //           (hd=64; frame attention 1029 keys, global attention 13377/21609 keys)
+//   UMT5  : transformers T5/UMT5 self-attention with additive relative-position bias (RELB variant, hd=64, <=512 tokens)
 //   VAE   : /root/reference/utils/wan_utils.py:460 (single head, 4096 tokens, C=384 -> handled as 3x128? no:
 //           the VAE mid-block attention uses the GEMM path)
 //
@@ -32,9 +33,12 @@ struct AttnP {
   int H, Nq, Nk;
   float scale_log2e;              // softmax scale * log2(e)
   int kv_period, kv_valid;        // kv_period > 0: key k takes part only if (k % kv_period) < kv_valid
+  const float* relb;              // RELB: additive bias by relative position, [H][relb_stride], index key - query + relb_center
+  int relb_stride, relb_center;
+  float inv_scale;                // bias is added to the raw score as bias / softmax_scale
 };
 
-template <int D, int NW>
+template <int D, int NW, bool RELB>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnP p) {
   constexpr int KV = 64;                 // keys per tile
   constexpr int KROWB = D * 2;           // bytes per K row in LDS
@@ -162,6 +166,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnP p) {
       }
     }
     // lane (q = l31, hi) now holds keys kt*64 + 32*t + 16*hi + r, r = 0..15
+    if constexpr (RELB) {  // T5-style relative position bias (UMT5 text encoder): 16 consecutive table entries per sub-tile
+      const float* tb = p.relb + (size_t)h * p.relb_stride + p.relb_center + (kt * KV + 16 * hi) - min(q0 + l31, p.Nq - 1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * KV + 32 * t + 16 * hi + r;
+          if (key < p.Nk) s[t][r] += tb[32 * t + r] * p.inv_scale;
+        }
+    }
     if (kt == nkt - 1 && (p.Nk & (KV - 1))) {
       const int kb = kt * KV + 16 * hi;
 #pragma unroll
@@ -262,13 +276,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnP p) {
   }
 }
 
-template <int D, int NW>
+template <int D, int NW, bool RELB>
 int launch_attn(const AttnP& p, int B, void* stream) {
   constexpr int STAGE = 64 * D * 2 + D * 128;
   constexpr int OBYTES = NW * 32 * (D * 2 + 8);
   constexpr int LDS = (2 * STAGE > OBYTES) ? 2 * STAGE : OBYTES;
   static bool attr = false;
-  auto fn = attn_fwd_kernel<D, NW>;
+  auto fn = attn_fwd_kernel<D, NW, RELB>;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return V3A_ERR_LAUNCH;
@@ -298,6 +312,12 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
   p.scale_log2e = a->scale * 1.4426950408889634f;
   p.kv_period = a->kv_period; p.kv_valid = a->kv_valid;
-  if (a->D == 128) return launch_attn<128, 4>(p, a->B, stream);
-  return launch_attn<64, 4>(p, a->B, stream);
+  p.relb = a->rel_bias; p.relb_stride = a->rel_bias_stride; p.relb_center = a->rel_bias_center;
+  p.inv_scale = 1.0f / a->scale;
+  if (a->rel_bias) {  // needs table entries for every (key - query) in [-(Nq-1), Nk-1]
+    if (a->D != 64 || a->rel_bias_center < a->Nq - 1 || a->rel_bias_stride < a->rel_bias_center + a->Nk) return V3A_ERR_SHAPE;
+    return launch_attn<64, 4, true>(p, a->B, stream);
+  }
+  if (a->D == 128) return launch_attn<128, 4, false>(p, a->B, stream);
+  return launch_attn<64, 4, false>(p, a->B, stream);
 }

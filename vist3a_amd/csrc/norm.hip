@@ -19,6 +19,7 @@ struct LnP {
   float eps;
   int x_f32, y_f32;
   int ig, is, io, og, os, oo;   // row remaps: in row = m + (m/ig)*is + io (ig>0), out row likewise
+  int rms;                      // 1: no mean subtraction
 };
 
 template <int CPL>
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
       for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
     }
   }
-  const float mean = wave_sum(sum) / (float)p.d;
+  const float mean = p.rms ? 0.f : wave_sum(sum) / (float)p.d;
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
@@ -271,6 +272,7 @@ extern "C" int v3a_layernorm(const v3a_layernorm_args* a, void* stream) {
   p.eps = a->eps; p.x_f32 = a->x_is_f32; p.y_f32 = a->y_is_f32;
   p.ig = a->in_row_group; p.is = a->in_row_skip; p.io = a->in_row_off;
   p.og = a->out_row_group; p.os = a->out_row_skip; p.oo = a->out_row_off;
+  p.rms = a->rms;
   const dim3 grid((a->M + 3) / 4);
   DISPATCH_CPL(layernorm_kernel, p, a->d, grid, stream);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;

@@ -83,6 +83,7 @@ class AttnArgs(C.Structure):
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int),
         ("scale", C.c_float), ("kv_period", C.c_int), ("kv_valid", C.c_int),
+        ("rel_bias", C.c_void_p), ("rel_bias_stride", C.c_int), ("rel_bias_center", C.c_int),
     ]
 
 
@@ -97,6 +98,7 @@ class LayerNormArgs(C.Structure):
         ("x_is_f32", C.c_int), ("y_is_f32", C.c_int),
         ("in_row_group", C.c_int), ("in_row_skip", C.c_int), ("in_row_off", C.c_int),
         ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
+        ("rms", C.c_int),
     ]
 
 

@@ -227,8 +227,12 @@ def attention(
     B: int, H: int, Nq: int, Nk: int, D: int,
     q_batch_stride: int, k_batch_stride: int, vt_batch_stride: int, o_batch_stride: int,
     scale: Optional[float] = None, kv_period: int = 0, kv_valid: int = 0,
+    rel_bias: Optional[torch.Tensor] = None, rel_bias_center: int = 0,
 ) -> torch.Tensor:
-    """q,k,out: 2-D views [B*N, >=H*D] (row stride = their stride(0)); vt: 2-D [H*D, >=B*vt_batch_stride]."""
+    """q,k,out: 2-D views [B*N, >=H*D] (row stride = their stride(0)); vt: 2-D [H*D, >=B*vt_batch_stride].
+    rel_bias (D=64 only): fp32 [H, n] table, entry (key - query + rel_bias_center) is added to the scaled score."""
+    if rel_bias is not None and (rel_bias.dtype != f32 or rel_bias.dim() != 2 or rel_bias.shape[0] != H or not rel_bias.is_contiguous()):
+        raise ValueError("rel_bias must be contiguous fp32 [H, n]")
     for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (out, "out")):
         _chk2d(t, n, (bf16,))
     args = L.AttnArgs(
@@ -236,6 +240,7 @@ def attention(
         q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride,
         q.stride(0), k.stride(0), vt.stride(0), out.stride(0),
         B, H, Nq, Nk, D, float(scale if scale is not None else D ** -0.5), kv_period, kv_valid,
+        _ptr(rel_bias), rel_bias.shape[1] if rel_bias is not None else 0, rel_bias_center,
     )
     L.check(L.load().v3a_attention_fwd_bf16(C.byref(args), _stream()), "v3a_attention_fwd_bf16")
     return out
@@ -246,9 +251,10 @@ def layernorm(
     weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
     scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
     rows_per_batch: int = 0, eps: float = 1e-6, out_dtype: torch.dtype = bf16,
-    M: Optional[int] = None, in_rows: tuple = (0, 0, 0), out_rows: tuple = (0, 0, 0),
+    M: Optional[int] = None, in_rows: tuple = (0, 0, 0), out_rows: tuple = (0, 0, 0), rms: bool = False,
 ) -> torch.Tensor:
-    """in_rows/out_rows = (group, skip, off): logical row m maps to physical row m + (m//group)*skip + off."""
+    """in_rows/out_rows = (group, skip, off): logical row m maps to physical row m + (m//group)*skip + off.
+    rms=True: no mean subtraction (T5LayerNorm)."""
     _chk2d(x, "x", (bf16, f32))
     d = x.shape[1]
     if M is None:
@@ -269,7 +275,7 @@ def layernorm(
     args = L.LayerNormArgs(
         _ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(scale), _ptr(shift),
         M, d, x.stride(0), out.stride(0), rows_per_batch, mstride, eps,
-        int(x.dtype == f32), int(out.dtype == f32), *in_rows, *out_rows,
+        int(x.dtype == f32), int(out.dtype == f32), *in_rows, *out_rows, int(rms),
     )
     L.check(L.load().v3a_layernorm(C.byref(args), _stream()), "v3a_layernorm")
     return out
