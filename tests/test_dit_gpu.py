@@ -144,3 +144,27 @@ def test_denoise_plan_matches_single_gpu_loop(tiny, world):
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o, ref)
+
+
+def test_graph_replay_is_bit_identical_across_steps_and_prompts(tiny):
+    """GraphedWanDiT: one captured hipGraph serves changing latents, timesteps and PROMPTS (persistent context buffers)."""
+    from vist3a_amd.wan.dit import GraphedWanDiT
+    ocfg, sd, model = tiny
+    gm = GraphedWanDiT(model)
+    g = torch.Generator().manual_seed(12)
+    texts = [(torch.randn(2, 64, ocfg.text_dim, generator=g) * 0.5).cuda() for _ in range(2)]
+    for rnd in range(2):
+        for text in texts:
+            for t in (900, 400):
+                lat = torch.randn(2, 16, 2, 16, 16, generator=g).to(torch.bfloat16).cuda()
+                tt = torch.tensor([t, t]).cuda()
+                want = model(lat, tt, text)[0].clone()
+                got = gm(lat, tt, text)[0].clone()
+                assert torch.equal(got, want)
+    assert len(gm._graphs) == 1
+    # in-place edit of the prompt tensor is noticed (version counter), a different latent shape captures a second graph
+    texts[0].mul_(0.5)
+    lat = torch.randn(2, 16, 1, 16, 16, generator=g).to(torch.bfloat16).cuda()
+    tt = torch.tensor([10, 10]).cuda()
+    assert torch.equal(gm(lat, tt, texts[0])[0], model(lat, tt, texts[0])[0])
+    assert len(gm._graphs) == 2

@@ -9,6 +9,7 @@
 Everything stays on the device and, between the VAE decoder and the reconstruction heads, in channels-last bf16."""
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -21,7 +22,7 @@ from .models.stitching_layer_builder import parse_conv_spec
 from .models.types import EncoderOutput
 from .recon.engine import ReconCfg
 from .recon.weights import random_recon_state_dict, round_aggregator_to_bf16
-from .wan.dit import WAN_1_3B, WanDiT, WanDiTConfig
+from .wan.dit import WAN_1_3B, GraphedWanDiT, WanDiT, WanDiTConfig
 from .wan.pipeline import WanT2VPipeline, denormalize_latents
 from .wan.scheduler import UniPCMultistepScheduler
 from .wan.vae import WanVAEConfig, WanVAEDecoder
@@ -37,10 +38,14 @@ class SceneTimes:
 
 class Text23DGS:
     def __init__(self, transformer: WanDiT, vae: WanVAEDecoder, stitched_decoder: StitchVAE3D, flow_shift: float = 5.0,
-                 feedforward_resolution: int = 448, device="cuda"):
+                 feedforward_resolution: int = 448, device="cuda", graph: Optional[bool] = None):
+        """graph: replay the DiT step from a captured hipGraph (default on; V3A_NO_GRAPH=1 turns it off for debugging)."""
         self.device = torch.device(device)
         self.transformer, self.vae, self.stitched_decoder = transformer, vae, stitched_decoder
-        self.pipe = WanT2VPipeline(transformer, UniPCMultistepScheduler(flow_shift=flow_shift), vae=vae, device=device)
+        if graph is None:
+            graph = os.environ.get("V3A_NO_GRAPH", "0") != "1"
+        step_fn = GraphedWanDiT(transformer) if graph else transformer
+        self.pipe = WanT2VPipeline(step_fn, UniPCMultistepScheduler(flow_shift=flow_shift), vae=vae, device=device)
         self.ff_res = feedforward_resolution
 
     @classmethod
