@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] == c:
                 acc[k] += float(r["Counter_Value"]); n[k] += 1
     for k in acc:
-        if "gemm_nt_kernel<256, 192, 4, 2, 64, 2, false, 0>" in k or "attn_fwd_kernel<128" in k:
+        if "gemm_nt_kernel<256, 192, 4, 2, 64, 2, false, 0, 1>" in k or "gemm_nt_kernel<256, 192, 4, 2, 32, 2, false, 0, 2>" in k or "attn_fwd_kernel3<128" in k:
             out.setdefault(k[:90], {})[c] = dict(avg_per_launch=acc[k] / n[k], launches=n[k])
 print(json.dumps(out, indent=1))
 PY
