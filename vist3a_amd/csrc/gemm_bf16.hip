@@ -14,6 +14,8 @@
 //     the wave's tile in LDS, and re-reads whole rows so that bias / activation / gate / residual and
 //     the global stores are all 16-byte coalesced.
 //   * workgroup ids are remapped so that each XCD (private 4 MiB L2) owns a contiguous run of tiles.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/vist3a_hip.h"
 #include <type_traits>
@@ -98,7 +100,19 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_
 
   const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
   const int t = xcd_remap(blockIdx.x, tilesM * tilesN);
-  const int m0 = (t / tilesN) * BM, n0 = (t % tilesN) * BN;
+  // Grouped raster: consecutive tiles walk down a band of GM row-tiles before moving to the next column, so the ~64 tiles in
+  // flight on one XCD (and the XCD's whole contiguous chunk) cover a near-square patch: 8 A row-panels + 8 W panels per 64
+  // tiles instead of 1-2 A panels + every W panel (FFN1: 535 MB -> ~260 MB of L2 fills per launch).
+  constexpr int GM = (OCC * 32 * BN / BM >= 36) ? 8 : 4;  // ~sqrt(tiles in flight per XCD x BN/BM): squarest in-flight patch
+  int tm, tn;
+  if (p.flags & (1 << 27)) {  // A/B switch: plain row-major order
+    tm = t / tilesN; tn = t % tilesN;
+  } else {
+    const int gsz = GM * tilesN, gid = t / gsz, first = gid * GM;
+    const int gm = min(tilesM - first, GM), r = t - gid * gsz;
+    tm = first + r % gm; tn = r / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- per-lane staging sources (advance by RB bytes per K slab) ----
   constexpr int NLA = T::NLA;
@@ -545,6 +559,7 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : 1; p.sstride = a->scale_stride;
   p.act = a->act; p.flags = a->flags;
+  { static const bool rowmajor = getenv("V3A_GEMM_ROWMAJOR") != nullptr; if (rowmajor) p.flags |= 1 << 27; }  // A/B switch
   p.res2 = (const char*)a->residual2; p.ldr2 = a->ldr2; p.res_mod = a->res_row_mod;
   p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
   if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
