@@ -581,6 +581,7 @@ extern "C" int v3a_conv_bf16(const v3a_conv_args* a, void* stream) {
   p.lda = 0; p.ldb = a->Kpad; p.ldc = a->ldy; p.ldr = a->ldr;
   p.rpb = 1; p.sstride = 0;
   p.act = a->act; p.flags = a->flags & ~V3A_GEMM_SCALE_PER_BATCH;
+  { static const bool rowmajor = getenv("V3A_GEMM_ROWMAJOR") != nullptr; if (rowmajor) p.flags |= 1 << 27; }  // A/B switch
   p.ktab = a->ktab;
   p.cT = a->T; p.cH = a->H; p.cW = a->W; p.cCin = a->Cin;
   p.oH = a->oH; p.oW = a->oW;
