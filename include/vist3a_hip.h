@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 4) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 5) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -206,6 +206,21 @@ int v3a_gaussian_adapter(const float* pts, const float* feats, int ldf, long U, 
 int v3a_linear_f32(const float* x, const float* w, const float* bias, float* y, const float* residual, const float* gamma,
                    int M, int N, int K, int ldx, int ldy, int ldr, int act, void* stream);
 int v3a_attention_small_f32(const float* qkv, float* out, int S, int H, int hd, float scale, void* stream);
+
+/* Skinny GEMM: X has M <= 128 rows, W [N][K] is streamed once (K % 512 == 0).  C[m][n] = act(X.W^T + bias[n]) (+ residual), or the
+ * transposed store C[n][m] (bias still indexed by n) for the V^T = Wv.X^T form.  Same rounding points as v3a_gemm_bf16_nt.
+ * Replaces nn.Linear on a prompt's tokens: transformers UMT5 q/k/v/o/wi_0/wi_1/wo (the text encoder behind
+ * diffusers WanPipeline.encode_prompt; /root/reference/utils/wan_utils.py:25-60). */
+typedef struct {
+  const void* X; const void* W; void* C;   /* bf16 X, W; C bf16 or fp32 (V3A_GEMM_OUT_F32) */
+  const float* bias;                        /* [N] or NULL */
+  const void* residual;                     /* C-shaped, bf16 or fp32 (V3A_GEMM_RES_F32), or NULL */
+  int M, N, K, ldx, ldw, ldc, ldr;
+  int act, flags, transposed_out;
+  void* workspace; long workspace_bytes;    /* v3a_gemm_skinny_workspace_bytes(M, N, K) */
+} v3a_gemm_skinny_args;
+long v3a_gemm_skinny_workspace_bytes(int M, int N, int K);
+int v3a_gemm_skinny_bf16(const v3a_gemm_skinny_args* a, void* stream);
 
 /* ---- 3D-Gaussian rasteriser: gsplat==1.4.0 `rasterization(..., render_mode="RGB+D", packed=False,
  * near_plane=1e-10, radius_clip=0.1, covars=..., rasterize_mode="classic")` as driven by

@@ -51,6 +51,15 @@ class ConvArgs(C.Structure):
     ]
 
 
+class GemmSkinnyArgs(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ldx", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int), ("ldr", C.c_int),
+        ("act", C.c_int), ("flags", C.c_int), ("transposed_out", C.c_int),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_long),
+    ]
+
+
 class GsProjectArgs(C.Structure):
     _fields_ = [
         ("means", C.c_void_p), ("covars", C.c_void_p), ("sh", C.c_void_p),
@@ -143,6 +152,8 @@ SYMBOLS = {
     "v3a_gaussian_adapter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_float] + [C.c_void_p] * 8),
     "v3a_linear_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
     "v3a_attention_small_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "v3a_gemm_skinny_workspace_bytes": (C.c_long, [C.c_int, C.c_int, C.c_int]),
+    "v3a_gemm_skinny_bf16": (C.c_int, [C.POINTER(GemmSkinnyArgs), C.c_void_p]),
     "v3a_gs_project": (C.c_int, [C.POINTER(GsProjectArgs), C.c_void_p]),
     "v3a_gs_rasterize_workspace_bytes": (C.c_long, [C.c_long, C.c_int, C.c_int, C.c_int, C.c_long]),
     "v3a_gs_rasterize": (C.c_int, [C.POINTER(GsRasterizeArgs), C.c_void_p]),

@@ -89,6 +89,13 @@ def gemm(
             raise ValueError("out_rows needs an explicit out tensor")
         out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
     _chk2d(out, "out", (f32,) if out_f32 else (bf16,))
+    # weight-streaming shapes (<= 128 rows against a big matrix) go to the skinny kernel: the tile GEMM would occupy N/128 CUs
+    plain = scale is None and residual2 is None and out_rows is None and not relu_out and tile < 0 and res_row_mod == 0
+    if plain and K % 512 == 0 and K >= 1024:
+        if M <= 128 and N >= 512 and not bias_row:
+            return _gemm_skinny(a, w, bias, out, act, residual, out_f32, transposed=False)
+        if N <= 128 and M >= 512 and (bias is None or bias_row):
+            return _gemm_skinny(w, a, bias, out, act, residual, out_f32, transposed=True)
     flags = L.GEMM_RELU_OUT if relu_out else 0
     if bias is not None:
         if bias.dtype != f32 or not bias.is_contiguous() or bias.numel() != (M if bias_row else N):
@@ -133,6 +140,39 @@ def gemm(
         pr.flops += 2.0 * M * N * K
         return out
     L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")
+    return out
+
+
+_skinny_ws = {}
+
+
+def _gemm_skinny(x, wbig, bias, out, act, residual, out_f32, transposed):
+    """x [Msmall<=128, K] against wbig [Nbig, K]: out[m][n] (or out[n][m] when transposed) through v3a_gemm_skinny_bf16."""
+    Ms, K = x.shape
+    Nb = wbig.shape[0]
+    if bias is not None and (bias.dtype != f32 or not bias.is_contiguous() or bias.numel() != Nb):
+        raise ValueError("bias must be contiguous f32 over the weight rows")
+    lib = L.load()
+    need = lib.v3a_gemm_skinny_workspace_bytes(Ms, Nb, K)
+    if need < 0:
+        L.check(int(need), "v3a_gemm_skinny_workspace_bytes")
+    key = x.device.index
+    ws = _skinny_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _skinny_ws[key] = torch.empty(max(need, 1 << 22), device=x.device, dtype=torch.uint8)
+    flags, ldr = 0, 0
+    if residual is not None:
+        _chk2d(residual, "residual", (bf16, f32))
+        if tuple(residual.shape) != tuple(out.shape):
+            raise ValueError("residual shape mismatch")
+        if residual.dtype == f32:
+            flags |= L.GEMM_RES_F32
+        ldr = residual.stride(0)
+    if out_f32:
+        flags |= L.GEMM_OUT_F32
+    args = L.GemmSkinnyArgs(_ptr(x), _ptr(wbig), _ptr(out), _ptr(bias), _ptr(residual), Ms, Nb, K, x.stride(0), wbig.stride(0),
+                            out.stride(0), ldr, act, flags, int(transposed), _ptr(ws), ws.numel())
+    L.check(lib.v3a_gemm_skinny_bf16(C.byref(args), _stream()), "v3a_gemm_skinny_bf16")
     return out
 
 
