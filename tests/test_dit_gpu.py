@@ -168,3 +168,34 @@ def test_graph_replay_is_bit_identical_across_steps_and_prompts(tiny):
     tt = torch.tensor([10, 10]).cuda()
     assert torch.equal(gm(lat, tt, texts[0])[0], model(lat, tt, texts[0])[0])
     assert len(gm._graphs) == 2
+
+
+def test_wan14b_width_two_blocks_matches_oracle(hip_lib):
+    """BASELINE config #4 geometry (Wan-14B: 40 heads x 128 = 5120 wide, FFN 13824) on two blocks: the GEMM tilings are ragged
+    there (5120 / 192, 13824 / 192 are not integers) — same tolerances as the 1.3B-width forward."""
+    from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
+    kw = dict(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=2, text_dim=256, freq_dim=256)
+    ocfg = O.WanDiTConfig(**kw)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=4).items()}
+    model = WanDiT(WanDiTConfig(**kw), sd, device="cuda")
+    g = torch.Generator().manual_seed(14)
+    lat = torch.randn(2, 16, 2, 16, 16, generator=g).to(torch.bfloat16)   # 128 tokens per item
+    text = (torch.randn(2, 48, 256, generator=g) * 0.5).to(torch.bfloat16).float()
+    t = torch.tensor([611, 611])
+    ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
+    out = model(lat.cuda(), t.cuda(), text.cuda())[0]
+    r = _rel(out, ref)
+    print("14B-width rel vs emu-oracle", r)
+    assert torch.isfinite(out.float()).all() and r < 1.5e-2, r
+
+
+def test_21_view_latent_shapes(tiny):
+    """BASELINE config #3 geometry: 21 views = 6 latent frames (6144 tokens at 64x64 latents; here 6 x 16 x 16 = 384)."""
+    ocfg, sd, model = tiny
+    g = torch.Generator().manual_seed(21)
+    lat = torch.randn(2, 16, 6, 32, 32, generator=g).to(torch.bfloat16)
+    text = (torch.randn(2, 40, ocfg.text_dim, generator=g) * 0.5).to(torch.bfloat16).float()
+    t = torch.tensor([333, 333])
+    ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
+    out = model(lat.cuda(), t.cuda(), text.cuda())[0]
+    assert out.shape == lat.shape and _rel(out, ref) < 1.5e-2
