@@ -4,8 +4,8 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from vist3a_amd.wan.vae import WanVAEConfig, WanVAEDecoder
-from oracle.wan_vae import make_weights, WanVAEConfig as OC
-sd = make_weights(OC(), seed=0)
+from vist3a_amd.t23d import random_vae_decoder_state_dict, random_vae_encoder_state_dict
+sd = random_vae_decoder_state_dict(WanVAEConfig(), seed=0)
 dec = WanVAEDecoder(WanVAEConfig(), sd)
 Tl = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 z = torch.randn(1, 16, Tl, 64, 64, device="cuda")
@@ -23,8 +23,7 @@ print(json.dumps(dict(vae_decode_ms=e0.elapsed_time(e1) / n, shape=list(o.shape)
 
 # encoder (StitchVAE3D.forward path): 13 views @512^2 -> latent [1,32,4,64,64]
 from vist3a_amd.wan.vae import WanVAEEncoder
-from oracle.wan_vae import make_encoder_weights
-enc = WanVAEEncoder(WanVAEConfig(), make_encoder_weights(OC(), seed=1))
+enc = WanVAEEncoder(WanVAEConfig(), random_vae_encoder_state_dict(WanVAEConfig(), seed=1))
 x = (torch.rand(1, 3, 1 + 4 * (Tl - 1), 512, 512, device="cuda") * 2 - 1)
 for _ in range(2):
     p = enc.encode_params(x)

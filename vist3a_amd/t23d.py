@@ -138,6 +138,52 @@ def random_vae_decoder_state_dict(cfg: WanVAEConfig, seed: int = 0, device="cpu"
     return sd
 
 
+def random_vae_encoder_state_dict(cfg: WanVAEConfig, seed: int = 0, device="cpu"):
+    """Seeded Wan-VAE encoder (+quant_conv) weights under the reference's names (utils/wan_utils.py:534-662, 990)."""
+    import math
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+
+    def conv(name, o, i, k):
+        sd[name + ".weight"] = torch.randn(o, i, *k, generator=g, device=device) / math.sqrt(i * math.prod(k))
+        sd[name + ".bias"] = torch.randn(o, generator=g, device=device) * 0.02
+
+    def gamma(name, c, nd):
+        sd[name + ".gamma"] = 1 + 0.05 * torch.randn(c, *([1] * nd), generator=g, device=device)
+
+    def res(p, i, o):
+        gamma(p + "norm1", i, 3); conv(p + "conv1", o, i, (3, 3, 3)); gamma(p + "norm2", o, 3); conv(p + "conv2", o, o, (3, 3, 3))
+        if i != o:
+            conv(p + "conv_shortcut", o, i, (1, 1, 1))
+
+    e = "encoder."
+    dims = [cfg.base_dim * u for u in [1] + cfg.dim_mult]
+    conv(e + "conv_in", dims[0], 3, (3, 3, 3))
+    idx = 0
+    for i, (i_d, o_d) in enumerate(zip(dims[:-1], dims[1:])):
+        cur = i_d
+        for _ in range(cfg.num_res_blocks):
+            res(e + f"down_blocks.{idx}.", cur, o_d)
+            cur = o_d
+            idx += 1
+        if i != len(cfg.dim_mult) - 1:
+            p = e + f"down_blocks.{idx}."
+            conv(p + "resample.1", o_d, o_d, (3, 3))
+            if cfg.temperal_downsample[i]:
+                conv(p + "time_conv", o_d, o_d, (3, 1, 1))
+            idx += 1
+    d = dims[-1]
+    res(e + "mid_block.resnets.0.", d, d)
+    gamma(e + "mid_block.attentions.0.norm", d, 2)
+    conv(e + "mid_block.attentions.0.to_qkv", 3 * d, d, (1, 1))
+    conv(e + "mid_block.attentions.0.proj", d, d, (1, 1))
+    res(e + "mid_block.resnets.1.", d, d)
+    gamma(e + "norm_out", d, 3)
+    conv(e + "conv_out", 2 * cfg.z_dim, d, (3, 3, 3))
+    conv("quant_conv", 2 * cfg.z_dim, 2 * cfg.z_dim, (1, 1, 1))
+    return sd
+
+
 def synthetic_text_embeddings(device="cuda", seed: int = 12413, L_pos: int = 64, L_neg: int = 80, max_len: int = 512, dim: int = 4096):
     """randn*0.1 rows for the first L tokens, zero rows after (the pipeline zero-pads to 512, no mask)."""
     g = torch.Generator().manual_seed(seed)
