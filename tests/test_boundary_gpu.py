@@ -116,3 +116,39 @@ def test_scene_pipeline_properties_reduced(hip_lib):
     cov = gs.covariances[0]
     assert torch.allclose(cov, cov.transpose(-1, -2), atol=1e-9) and (torch.linalg.eigvalsh(cov.double().cpu()) > -1e-9).all()
     assert gs.means.shape[1] <= 5 * 448 * 448
+
+
+def test_rccl_backend_single_rank_all_gather(hip_lib, tmp_path):
+    """`DistGroup` on the real RCCL backend (one rank is all a 1-GPU box offers): process-group bring-up via setup_dist,
+    asynchronous all_gather_into_tensor on device tensors, wait() ordering the compute stream."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    script = tmp_path / "rccl1.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {str(root)!r})
+import torch, torch.distributed as dist
+from vist3a_amd.utils.dist_util import setup_dist
+from vist3a_amd.wan.seqpar import DenoisePlan, DistGroup
+setup_dist()
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+plan = DenoisePlan.from_dist()
+assert plan.sp is None and plan.cfg is None          # one rank: nothing to shard
+g = DistGroup([0], 0, dist.group.WORLD)
+x = torch.arange(1 << 20, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+out = torch.empty(1, x.numel(), device="cuda", dtype=torch.bfloat16)
+h = g.all_gather(out, x)
+h.wait()
+y = out[0].float().sum()                              # consumer on the compute stream, ordered after the collective
+torch.cuda.synchronize()
+assert torch.equal(out[0], x) and float(y) == float(x.float().sum())
+dist.destroy_process_group()
+print("rccl ok")
+""")
+    import os
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
