@@ -199,3 +199,70 @@ def test_21_view_latent_shapes(tiny):
     ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
     out = model(lat.cuda(), t.cuda(), text.cuda())[0]
     assert out.shape == lat.shape and _rel(out, ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("Nk", [4096, 512, 1000])
+def test_attention_is_run_to_run_deterministic_at_full_size(hip_lib, Nk):
+    """Regression: with the single-buffered V^T tile a wave used to pass the end-of-tile barrier with a fragment read still in
+    flight (hipcc sinks the last MFMA and its lgkmcnt wait below a bare s_barrier) while another wave's DMA refilled the buffer —
+    visible only at production size as whole 32-row groups differing between runs."""
+    from vist3a_amd import ops
+    B, H, N, D = 2, 12, 4096, 128
+    d = H * D
+    g = torch.Generator(device="cuda").manual_seed(Nk)
+    q = (torch.randn(B * N, d, device="cuda", generator=g) * 0.5).bfloat16()
+    k = (torch.randn(B * Nk, d, device="cuda", generator=g) * 0.5).bfloat16()
+    Lp = (Nk + 63) // 64 * 64
+    vt = torch.zeros(d, B * Lp, device="cuda", dtype=torch.bfloat16)
+    for b in range(B):
+        vt[:, b * Lp: b * Lp + Nk] = torch.randn(d, Nk, device="cuda", generator=g).bfloat16()
+    outs = []
+    for _ in range(5):
+        o = torch.empty(B * N, d, device="cuda", dtype=torch.bfloat16)
+        ops.attention(q, k, vt, o, B=B, H=H, Nq=N, Nk=Nk, D=D, q_batch_stride=N * d, k_batch_stride=Nk * d, vt_batch_stride=Lp,
+                      o_batch_stride=N * d)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    qf, kf, vf = q[:N, :D].float(), k[:Nk, :D].float(), vt[:D, :Nk].float().t()
+    ref = torch.softmax(qf @ kf.t() * D ** -0.5, -1) @ vf
+    assert _rel(outs[0][:N, :D], ref) < 3e-3
+
+
+def test_full_size_dit_forward_is_deterministic_and_batch_independent(hip_lib):
+    """Two production-width blocks at 4096 tokens: identical across runs, and the CFG pair (B=2) equals two B=1 forwards."""
+    from vist3a_amd.wan.dit import WAN_1_3B, WanDiT
+    from vist3a_amd.wan.weights import random_dit_state_dict
+    import dataclasses
+    cfg = dataclasses.replace(WAN_1_3B, num_layers=2)
+    m = WanDiT(cfg, random_dit_state_dict(cfg, seed=0, device="cuda"))
+    g = torch.Generator().manual_seed(1)
+    text = (torch.randn(2, 512, 4096, generator=g) * 0.1).cuda()
+    lat = torch.randn(2, 16, 4, 64, 64, generator=g).bfloat16().cuda()
+    t = torch.tensor([900, 900]).cuda()
+    a = m(lat, t, text)[0].clone()
+    b = m(lat, t, text)[0].clone()
+    one = torch.cat([m(lat[i:i + 1], t[i:i + 1], text[i:i + 1].contiguous())[0].clone() for i in range(2)], 0)
+    assert torch.equal(a, b) and torch.equal(a, one)
+
+
+def test_prompt_context_cache_survives_address_reuse(tiny):
+    """Regression: the per-prompt cross-attention cache was keyed by data_ptr; a new prompt whose embedding tensor was allocated at
+    the address of the previous (freed) one got the OLD prompt's K / V."""
+    from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
+    ocfg, sd, model = tiny
+    fresh = WanDiT(WanDiTConfig(**TINY), sd, device="cuda")
+    g = torch.Generator().manual_seed(33)
+    lat = torch.randn(2, 16, 2, 16, 16, generator=g).to(torch.bfloat16).cuda()
+    t = torch.tensor([700, 700]).cuda()
+    a_cpu = torch.randn(2, 64, ocfg.text_dim, generator=g) * 0.5
+    b_cpu = torch.randn(2, 64, ocfg.text_dim, generator=g) * 0.5
+    text = a_cpu.cuda()
+    ptr = text.data_ptr()
+    model(lat, t, text)
+    del text
+    text = b_cpu.cuda()            # the caching allocator hands the same block back
+    same_addr = text.data_ptr() == ptr
+    out = model(lat, t, text)[0].clone()
+    want = fresh(lat, t, b_cpu.cuda())[0]
+    assert torch.equal(out, want), f"stale prompt context (address reused: {same_addr})"

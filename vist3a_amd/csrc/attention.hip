@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnP p) {
         oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c4], oacc[i], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // reads retired too: the compiler may sink the last MFMA below
     __builtin_amdgcn_s_barrier();
   }
 
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
     // V^T pieces were issued before the K pieces: leave the K prefetch in flight
     if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();  // every wave's V^T pieces have landed
     // O^T += V^T . P^T
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
@@ -493,7 +493,10 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
         oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c4], oacc[i], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lgkmcnt(0) is essential: hipcc sinks the last PV MFMA (and the wait for its V^T fragment read) BELOW the barrier, so a
+    // wave would pass it with an LDS read of the single V^T buffer still in flight while a faster wave's next-tile DMA
+    // overwrites that buffer (seen as run-to-run differences in whole 32-row groups)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 

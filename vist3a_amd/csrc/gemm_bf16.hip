@@ -251,8 +251,10 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_
   // one K slab: wait for its DMA (counted), barrier, then MFMA groups with the refill DMA spread between them
   auto slab = [&](auto more_tag, auto drain_tag) {
     constexpr bool MORE = decltype(more_tag)::value, DRAIN = decltype(drain_tag)::value;
-    if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::NLMIN * (NS - 2)) : "memory");
+    // lgkmcnt(0): every fragment read of the previous slab has RETURNED before this wave lets others refill that slot (the
+    // compiler is free to sink the last MFMAs, and the waits for their operands, below a bare s_barrier)
+    if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(T::NLMIN * (NS - 2)) : "memory");
     __builtin_amdgcn_s_barrier();  // slab visible to all waves; everyone is done reading the slot about to be refilled
     if constexpr (MORE) stage(fill, 0, 1);  // measured: issuing the refill up front beats spreading it between MFMA groups
     const char* sA = smem + slot * STAGE + aoff;
@@ -318,7 +320,10 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_
     if (kt + 1 < nk) { slab(kt & 1, TT{}, FF{}); ++kt; }
     if (kt < nk) slab(kt & 1, FF{}, FF{});
   }
-  if constexpr (STG == 0) __builtin_amdgcn_s_barrier();  // all fragment reads retired before the ring is reused by the epilogue
+  if constexpr (STG == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // all fragment reads retired before the ring is reused by the epilogue
+  }
 
   if (p.flags & (1 << 29)) {  // DEBUG/profiling only: skip the epilogue (accumulators kept live by a never-taken store)
     float sum = 0.f;

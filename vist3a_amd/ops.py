@@ -5,6 +5,7 @@ libvist3a_hip.so.  Every wrapper validates dtype/device/contiguity and raises on
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional
 
 import torch
@@ -156,7 +157,9 @@ def _gemm_skinny(x, wbig, bias, out, act, residual, out_f32, transposed):
     need = lib.v3a_gemm_skinny_workspace_bytes(Ms, Nb, K)
     if need < 0:
         L.check(int(need), "v3a_gemm_skinny_workspace_bytes")
-    key = x.device.index
+    # per stream and per host thread: the partial sums are live until the finish kernel, and two threads (virtual ranks of
+    # seqpar.ThreadWorld) may be inside the two-launch C call at the same time
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream, threading.get_ident())
     ws = _skinny_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _skinny_ws[key] = torch.empty(max(need, 1 << 22), device=x.device, dtype=torch.uint8)

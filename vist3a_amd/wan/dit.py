@@ -172,10 +172,12 @@ class WanDiT:
         per (B, L) (so a captured hipGraph of `forward` stays valid across prompts) and are recomputed only when `text` changes."""
         B, Lt, _ = text.shape
         slot = (B, Lt, threading.get_ident())  # per thread: virtual ranks (seqpar.ThreadWorld) hold different prompts
-        key = (text.data_ptr(), tuple(text.shape), text._version)
+        # identity of the tensor OBJECT (kept alive by the cache entry, so its address cannot be recycled for another prompt's
+        # embeddings while the entry is live) + its in-place version counter
         ent = self._ctx.get(slot)
-        if ent is not None and ent[0] == key:
+        if ent is not None and ent[0][0] is text and ent[0][1] == text._version:
             return ent[1]
+        key = (text, text._version)
         cfg = self.cfg
         d = cfg.dim
         Lp = (Lt + 63) // 64 * 64
