@@ -87,6 +87,7 @@ def main(args):
         print(f"[rank {rank}] {save}: {g.means.shape[1]} gaussians", flush=True)
     if world > 1:
         dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":
