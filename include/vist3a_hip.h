@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 5) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 6) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -122,6 +122,9 @@ typedef struct {
   const float* rel_bias;    /* optional (D = 64 only): additive bias by relative position, fp32 [H][rel_bias_stride], entry
                              * (key - query + rel_bias_center) is added to scale*q.k — T5/UMT5 relative attention bias */
   int rel_bias_stride, rel_bias_center;
+  const float* key_bias;    /* optional (D = 128 only): additive per-key bias, fp32 [B][key_bias_stride >= Nk], added to scale*q.k.
+                             * Used to merge the identical zero-padding keys of a prompt into one key carrying log(count). */
+  int key_bias_stride;
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 

@@ -266,3 +266,30 @@ def test_prompt_context_cache_survives_address_reuse(tiny):
     out = model(lat, t, text)[0].clone()
     want = fresh(lat, t, b_cpu.cuda())[0]
     assert torch.equal(out, want), f"stale prompt context (address reused: {same_addr})"
+
+
+def test_merged_padding_keys_equal_full_cross_attention(tiny):
+    """Zero-padded prompt: cross-attention over n real keys + ONE padding key with bias log(count) == attention over all 512 keys
+    (exact in real arithmetic; bf16 P rounding differs: 2e-3), and an unpadded prompt takes the plain path."""
+    from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
+    ocfg, sd, model = tiny
+    plain = WanDiT(WanDiTConfig(**TINY), sd, device="cuda")
+    plain.merge_padding_keys = False
+    g = torch.Generator().manual_seed(44)
+    lat = torch.randn(2, 16, 2, 16, 16, generator=g).to(torch.bfloat16).cuda()
+    t = torch.tensor([500, 500]).cuda()
+    text = torch.zeros(2, 512, ocfg.text_dim)
+    text[0, :37] = torch.randn(37, ocfg.text_dim, generator=g) * 0.5
+    text[1, :80] = torch.randn(80, ocfg.text_dim, generator=g) * 0.5
+    text = text.cuda()
+    a = model(lat, t, text)[0]
+    b = plain(lat, t, text)[0]
+    assert any(v[1][5] == 88 and v[1][6] for v in model._ctx.values())  # 80 real rows, padded to a multiple of 8: 88 keys
+    assert _rel(a, b) < 2e-3
+    ref = O.dit_forward(sd, ocfg, lat.float().cpu(), t.cpu(), text.cpu().to(torch.bfloat16).float(), emulate_bf16=True)
+    assert _rel(a, ref) < 1.5e-2
+    full = (torch.randn(2, 512, ocfg.text_dim, generator=g) * 0.5).cuda()       # nothing to merge
+    assert torch.equal(model(lat, t, full)[0], plain(lat, t, full)[0])
+    one_pad = full.clone()
+    one_pad[:, -1] = 0                                                           # a single zero row is not worth a merge
+    assert torch.equal(model(lat, t, one_pad)[0], plain(lat, t, one_pad)[0])

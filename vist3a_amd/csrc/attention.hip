@@ -42,6 +42,8 @@ struct AttnP {
   const float* relb;              // RELB: additive bias by relative position, [H][relb_stride], index key - query + relb_center
   int relb_stride, relb_center;
   float inv_scale;                // bias is added to the raw score as bias / softmax_scale
+  const float* kbias;             // KBIAS: additive per-key bias [B][kbias_stride] (log-multiplicity of merged identical keys)
+  int kbias_stride;
 };
 
 template <int D, int NW, bool RELB>
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnP p) {
 // Variant with THREE workgroups per CU (98304 query rows = 12 waves of 32 per CU: 3 x 4 waves is one exact round where
 // 2 x 4 leaves a half-filled second round).  LDS per workgroup 48 KB: K double-buffered, V^T single-buffered and fetched
 // while S = K.Q^T and the softmax run; two barriers per tile, hidden by the other two workgroups.
-template <int D, int NW>
+template <int D, int NW, bool KBIAS>
 __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
   constexpr bool RELB = false;
   constexpr int KV = 64;                 // keys per tile
@@ -417,6 +419,15 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
       }
     }
     // lane (q = l31, hi) now holds keys kt*64 + 32*t + 16*hi + r, r = 0..15
+    if constexpr (KBIAS) {  // per-key additive bias (cross-attention over a zero-padded prompt: the identical padding keys are
+                            // merged into ONE key carrying log(count)); 16 consecutive entries per sub-tile and lane
+      const float* kb = p.kbias + (size_t)b * p.kbias_stride + kt * KV + 16 * hi;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * KV + 32 * t + 16 * hi + r < p.Nk) s[t][r] += kb[32 * t + r] * p.inv_scale;
+    }
     if constexpr (RELB) {  // T5-style relative position bias (UMT5 text encoder): 16 consecutive table entries per sub-tile
       const float* tb = p.relb + (size_t)h * p.relb_stride + p.relb_center + (kt * KV + 16 * hi) - min(q0 + l31, p.Nq - 1);
 #pragma unroll
@@ -551,13 +562,13 @@ int launch_attn(const AttnP& p, int B, void* stream) {
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
-template <int D, int NW>
+template <int D, int NW, bool KBIAS>
 int launch_attn3(const AttnP& p, int B, void* stream) {
   constexpr int KT = 64 * D * 2, VT = D * 128;
   constexpr int OBYTES = NW * 32 * (D * 2 + 8);
   constexpr int LDS = (2 * KT + VT > OBYTES) ? 2 * KT + VT : OBYTES;
   static bool attr = false;
-  auto fn = attn_fwd_kernel3<D, NW>;
+  auto fn = attn_fwd_kernel3<D, NW, KBIAS>;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return V3A_ERR_LAUNCH;
@@ -594,6 +605,11 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
     return launch_attn<64, 4, true>(p, a->B, stream);
   }
   static const bool two_per_cu = getenv("V3A_ATTN_OCC2") != nullptr;  // A/B switch for the older 2-workgroup schedule
-  if (a->D == 128) return two_per_cu ? launch_attn<128, 4, false>(p, a->B, stream) : launch_attn3<128, 4>(p, a->B, stream);
+  p.kbias = a->key_bias; p.kbias_stride = a->key_bias_stride;
+  if (a->key_bias) {
+    if (a->D != 128 || a->rel_bias || a->key_bias_stride < a->Nk) return V3A_ERR_SHAPE;
+    return launch_attn3<128, 4, true>(p, a->B, stream);
+  }
+  if (a->D == 128) return two_per_cu ? launch_attn<128, 4, false>(p, a->B, stream) : launch_attn3<128, 4, false>(p, a->B, stream);
   return launch_attn<64, 4, false>(p, a->B, stream);  // recon (hd = 64): the 3-per-CU schedule measured no gain there
 }

@@ -124,6 +124,7 @@ class WanDiT:
         self._ws: Dict[tuple, _Workspace] = {}
         self._rope: Dict[tuple, torch.Tensor] = {}
         self._ctx: Dict[tuple, tuple] = {}  # (B, L, thread) -> (prompt key, persistent cross-attention K / V^T buffers)
+        self.merge_padding_keys = True      # see _context
         self._load(state_dict)
 
     # ---------------------------------------------------------------- weights
@@ -168,8 +169,14 @@ class WanDiT:
 
     # ---------------------------------------------------------------- context (per prompt)
     def _context(self, text: torch.Tensor):
-        """text [B,L,4096] -> per-block cross-attention K [B*L,d] and V^T [d,B*Lp].  The results live in buffers that persist
-        per (B, L) (so a captured hipGraph of `forward` stays valid across prompts) and are recomputed only when `text` changes."""
+        """text [B,L,4096] -> per-block cross-attention K [B*L,d] and V^T [d,B*Lp] (+ key bias).  The results live in buffers that
+        persist per (B, L) (so a captured hipGraph of `forward` stays valid across prompts) and are recomputed only when `text`
+        changes.
+
+        Zero-padded prompts (the reference pads every prompt to 512 rows with zeros: wan_utils.py:52-59 / diffusers
+        `_get_t5_prompt_embeds`): all-zero embedding rows give bit-identical keys and values, so the trailing run of `c` padding
+        rows is represented by ONE key with an additive score bias log(c) — softmax over {k_1..k_n, c copies of k_pad} is
+        softmax over {k_1..k_n, k_pad + log c} in exact arithmetic.  Cross-attention then runs over n+1 instead of 512 keys."""
         B, Lt, _ = text.shape
         slot = (B, Lt, threading.get_ident())  # per thread: virtual ranks (seqpar.ThreadWorld) hold different prompts
         # identity of the tensor OBJECT (kept alive by the cache entry, so its address cannot be recycled for another prompt's
@@ -184,17 +191,31 @@ class WanDiT:
         if ent is None:
             ks = [torch.empty(B * Lt, d, device=self.device, dtype=bf16) for _ in self.blocks]
             vts = [torch.zeros(d, B * Lp, device=self.device, dtype=bf16) for _ in self.blocks]
+            kbias = torch.zeros(B, Lp, device=self.device, dtype=f32)
         else:
-            ks, vts = ent[1][0], ent[1][1]
+            ks, vts, kbias = ent[1][0], ent[1][1], ent[1][4]
+        # trailing all-zero rows (one host sync per prompt)
+        nz = (text != 0).any(dim=-1)                                   # [B, Lt]
+        last = torch.where(nz.any(dim=1), Lt - 1 - nz.flip(1).float().argmax(dim=1), torch.full((B,), -1, device=text.device))
+        n_real = int(last.max().item()) + 1                            # rows [n_real, Lt) are zero for every batch item
+        Lk = (n_real + 1 + 7) // 8 * 8                                  # real rows + explicit padding rows up to a multiple of 8
+        merged = self.merge_padding_keys and Lk + 1 < Lt               # ... the last of which stands for all remaining ones
+        if not merged:
+            Lk = Lt                                                    # keys per batch item actually attended to
+        kbias.zero_()
+        if merged:
+            kbias[:, Lk - 1] = math.log(Lt - (Lk - 1))
         t2 = text.reshape(B * Lt, -1).to(bf16).contiguous()
         c = ops.gemm(t2, self.tx1_w, self.tx1_b, act=L.ACT_GELU_TANH)
         c = ops.gemm(c, self.tx2_w, self.tx2_b)
         for b, k, vt in zip(self.blocks, ks, vts):
-            ops.gemm(c, b["wk2"], b["bk2"], out=k)
-            ops.rmsnorm_rope(k, b["nk2"], out=k, eps=cfg.eps)
-            for bi in range(B):  # V^T per batch item so each lands at its 64-padded column block
-                ops.gemm(b["wv2"], c[bi * Lt:(bi + 1) * Lt], b["bv2"], out=vt[:, bi * Lp: bi * Lp + Lt], bias_row=True)
-        self._ctx[slot] = (key, (ks, vts, Lt, Lp))
+            for bi in range(B):  # the first Lk rows of every batch item (merged: row Lk-1 represents all padding rows from there on)
+                rows = slice(bi * Lt, bi * Lt + Lk)
+                ops.gemm(c[rows], b["wk2"], b["bk2"], out=k[rows])
+                ops.rmsnorm_rope(k[rows], b["nk2"], out=k[rows], eps=cfg.eps)
+                # V^T per batch item so each lands at its 64-padded column block
+                ops.gemm(b["wv2"], c[rows], b["bv2"], out=vt[:, bi * Lp: bi * Lp + Lk], bias_row=True)
+        self._ctx[slot] = (key, (ks, vts, Lt, Lp, kbias, Lk, merged))
         return self._ctx[slot][1]
 
     # ---------------------------------------------------------------- forward
@@ -220,7 +241,7 @@ class WanDiT:
         if rope is None:
             rope = self._rope[(ppf, pph, ppw)] = rope_table(cfg, ppf, pph, ppw, self.device)
         rope = rope[rk * Nl:(rk + 1) * Nl]
-        ks, vts, Lt, Lp = self._context(encoder_hidden_states)
+        ks, vts, Lt, Lp, kbias, Lk, merged = self._context(encoder_hidden_states)
 
         # patchify: Conv3d(k=s=(1,2,2)) == GEMM over (c,pt,ph,pw)-major patches
         x5 = hidden_states.to(bf16).view(B, C, ppf, pt, pph, ph, ppw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
@@ -279,8 +300,8 @@ class WanDiT:
             ops.layernorm(x, out=ws.n, weight=b["n2w"], bias=b["n2b"], eps=cfg.eps)
             ops.gemm(ws.n, b["wq2"], b["bq2"], out=ws.q2)
             ops.rmsnorm_rope(ws.q2, b["nq2"], out=ws.q2, eps=cfg.eps)
-            ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lt, D=hd, q_batch_stride=Nl * d,
-                          k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d)
+            ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lk, D=hd, q_batch_stride=Nl * d,
+                          k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d, key_bias=kbias if merged else None)
             ops.gemm(ws.ao, b["wo2"], b["bo2"], out=x, residual=x)
             # --- feed forward
             ops.layernorm(x, out=ws.n, scale=m[:, 4], shift=m[:, 3], rows_per_batch=Nl, eps=cfg.eps)
@@ -319,8 +340,8 @@ class GraphedWanDiT:
         if sp is not None or num_layers is not None or (pr is not None and pr.active):
             return self.dit.forward(hidden_states, timestep, encoder_hidden_states, return_dict, num_layers, sp)
         text = encoder_hidden_states
-        self.dit._context(text)  # eager: refreshes the persistent K / V^T buffers when the prompt changed
-        key = (tuple(hidden_states.shape), tuple(text.shape), threading.get_ident())
+        lk = self.dit._context(text)[5]  # eager: refreshes the persistent K / V^T buffers when the prompt changed
+        key = (tuple(hidden_states.shape), tuple(text.shape), lk, threading.get_ident())
         ent = self._graphs.get(key)
         if ent is None:
             sx = torch.empty(hidden_states.shape, device=self.device, dtype=bf16)
