@@ -125,6 +125,7 @@ typedef struct {
   const float* key_bias;    /* optional (D = 128 only): additive per-key bias, fp32 [B][key_bias_stride >= Nk], added to scale*q.k.
                              * Used to merge the identical zero-padding keys of a prompt into one key carrying log(count). */
   int key_bias_stride;
+  int key_bias_first;       /* keys < key_bias_first have zero bias (their tiles skip the bias loads); 0 = any key may carry bias */
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 

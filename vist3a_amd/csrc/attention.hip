@@ -43,7 +43,7 @@ struct AttnP {
   int relb_stride, relb_center;
   float inv_scale;                // bias is added to the raw score as bias / softmax_scale
   const float* kbias;             // KBIAS: additive per-key bias [B][kbias_stride] (log-multiplicity of merged identical keys)
-  int kbias_stride;
+  int kbias_stride, kbias_first;  // keys below kbias_first have zero bias: tiles entirely below it skip the loads
 };
 
 template <int D, int NW, bool RELB>
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
       }
     }
     // lane (q = l31, hi) now holds keys kt*64 + 32*t + 16*hi + r, r = 0..15
-    if constexpr (KBIAS) {  // per-key additive bias (cross-attention over a zero-padded prompt: the identical padding keys are
+    if (KBIAS && (kt + 1) * KV > p.kbias_first) {  // per-key additive bias (cross-attention over a zero-padded prompt: the identical padding keys are
                             // merged into ONE key carrying log(count)); 16 consecutive entries per sub-tile and lane
       const float* kb = p.kbias + (size_t)b * p.kbias_stride + kt * KV + 16 * hi;
 #pragma unroll
@@ -605,7 +605,7 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
     return launch_attn<64, 4, true>(p, a->B, stream);
   }
   static const bool two_per_cu = getenv("V3A_ATTN_OCC2") != nullptr;  // A/B switch for the older 2-workgroup schedule
-  p.kbias = a->key_bias; p.kbias_stride = a->key_bias_stride;
+  p.kbias = a->key_bias; p.kbias_stride = a->key_bias_stride; p.kbias_first = a->key_bias_first > 0 ? a->key_bias_first : 0;
   if (a->key_bias) {
     if (a->D != 128 || a->rel_bias || a->key_bias_stride < a->Nk) return V3A_ERR_SHAPE;
     return launch_attn3<128, 4, true>(p, a->B, stream);

@@ -93,7 +93,7 @@ class AttnArgs(C.Structure):
         ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int),
         ("scale", C.c_float), ("kv_period", C.c_int), ("kv_valid", C.c_int),
         ("rel_bias", C.c_void_p), ("rel_bias_stride", C.c_int), ("rel_bias_center", C.c_int),
-        ("key_bias", C.c_void_p), ("key_bias_stride", C.c_int),
+        ("key_bias", C.c_void_p), ("key_bias_stride", C.c_int), ("key_bias_first", C.c_int),
     ]
 
 

@@ -271,6 +271,7 @@ def attention(
     q_batch_stride: int, k_batch_stride: int, vt_batch_stride: int, o_batch_stride: int,
     scale: Optional[float] = None, kv_period: int = 0, kv_valid: int = 0,
     rel_bias: Optional[torch.Tensor] = None, rel_bias_center: int = 0, key_bias: Optional[torch.Tensor] = None,
+    key_bias_first: int = 0,
 ) -> torch.Tensor:
     """q,k,out: 2-D views [B*N, >=H*D] (row stride = their stride(0)); vt: 2-D [H*D, >=B*vt_batch_stride].
     rel_bias (D=64 only): fp32 [H, n] table, entry (key - query + rel_bias_center) is added to the scaled score.
@@ -287,7 +288,7 @@ def attention(
         q.stride(0), k.stride(0), vt.stride(0), out.stride(0),
         B, H, Nq, Nk, D, float(scale if scale is not None else D ** -0.5), kv_period, kv_valid,
         _ptr(rel_bias), rel_bias.shape[1] if rel_bias is not None else 0, rel_bias_center,
-        _ptr(key_bias), key_bias.stride(0) if key_bias is not None else 0,
+        _ptr(key_bias), key_bias.stride(0) if key_bias is not None else 0, key_bias_first,
     )
     L.check(L.load().v3a_attention_fwd_bf16(C.byref(args), _stream()), "v3a_attention_fwd_bf16")
     return out

@@ -301,7 +301,8 @@ class WanDiT:
             ops.gemm(ws.n, b["wq2"], b["bq2"], out=ws.q2)
             ops.rmsnorm_rope(ws.q2, b["nq2"], out=ws.q2, eps=cfg.eps)
             ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lk, D=hd, q_batch_stride=Nl * d,
-                          k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d, key_bias=kbias if merged else None)
+                          k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d, key_bias=kbias if merged else None,
+                          key_bias_first=Lk - 1)
             ops.gemm(ws.ao, b["wo2"], b["bo2"], out=x, residual=x)
             # --- feed forward
             ops.layernorm(x, out=ws.n, scale=m[:, 4], shift=m[:, 3], rows_per_batch=Nl, eps=cfg.eps)
