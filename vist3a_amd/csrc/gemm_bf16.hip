@@ -75,6 +75,141 @@ struct TileCfg {
   static_assert(BM % 32 == 0, "swizzle assumes B rows start at a multiple of 32");
 };
 
+// Epilogue shared by every main loop: the wave owns an (MT*32) x (NTL*32) output tile whose 32x32 blocks sit in acc[i][j] in
+// D^T orientation (lane (l31, hi) holds rows m = l31, 4 consecutive columns per accumulator quad).  Per 32-row group:
+//   phase 1: acc + bias -> bf16 -> this wave's private LDS region (32 rows x WTN)
+//   phase 2: whole-row re-read, fused elementwise, 16-byte coalesced stores
+template <int MT, int NTL>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane,
+                                              int mw0, int nw) {
+  constexpr int WTN = NTL * 32, PITCH = WTN * 2 + 8;
+  const int hi = lane >> 5, l31 = lane & 31;
+  char* reg = smem + wave * (32 * PITCH);
+  const bool bias_row = (p.flags & V3A_GEMM_BIAS_ROW) != 0;
+  constexpr int CH = WTN / 8;
+  constexpr int ITERS = 32 * CH / 64;
+  static_assert((32 * CH) % 64 == 0, "epilogue chunking");
+  const int act = p.act, flags = p.flags;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int mw = mw0 + i * 32;
+    {
+      const int ml = l31;
+      float brow = 0.f;
+      if (p.bias && bias_row) {
+        int m = mw + ml;
+        brow = p.bias[m < p.M ? m : p.M - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = j * 32 + g * 8 + hi * 4;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+          if (p.bias) {
+            if (bias_row) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += brow;
+            } else {
+              const int n = nw + nl;
+              if (n + 3 < p.N) {
+                const f32x4 bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bv[e];
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (n + e < p.N) v[e] += p.bias[n + e];
+              }
+            }
+          }
+          u32x2 pk;
+          pk[0] = pack_bf16x2(v[0], v[1]);
+          pk[1] = pack_bf16x2(v[2], v[3]);
+          *(u32x2*)(reg + ml * PITCH + nl * 2) = pk;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+    for (int it = 0; it < ITERS; ++it) {
+    const int idx = it * 64 + lane;
+    const int ml = idx / CH, ch = idx % CH;
+    const int m = mw + ml, n = nw + ch * 8;
+    const u32x2 lo = *(const u32x2*)(reg + ml * PITCH + ch * 16);
+    const u32x2 hi2 = *(const u32x2*)(reg + ml * PITCH + ch * 16 + 8);
+    if (m >= p.M || n >= p.N) continue;
+    u32x4 raw;
+    raw[0] = lo[0]; raw[1] = lo[1]; raw[2] = hi2[0]; raw[3] = hi2[1];
+    float v[8];
+    unpack_bf16x8(raw, v);
+    if (act != V3A_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[e];
+        if (act == V3A_ACT_GELU_TANH) x = gelu_tanh(x);
+        else if (act == V3A_ACT_GELU_ERF) x = gelu_erf(x);
+        else if (act == V3A_ACT_SILU) x = silu(x);
+        else x = fmaxf(x, 0.f);
+        v[e] = round_bf16(x);
+      }
+    }
+    if (p.scale) {
+      const float* sp = p.scale + ((flags & V3A_GEMM_SCALE_PER_BATCH) ? (size_t)(m / p.rpb) * p.sstride : 0) + n;
+      const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] *= s0[e]; v[4 + e] *= s1[e]; }
+      if (flags & V3A_GEMM_ROUND_AFTER_SCALE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e]);
+      }
+    }
+    if (p.res) {
+      const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+      if (flags & V3A_GEMM_RES_F32) {
+        const float* rp = (const float*)p.res + (size_t)mr * p.ldr + n;
+        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+      } else {
+        const u32x4 rr = *(const u32x4*)(p.res + ((size_t)mr * p.ldr + n) * 2);
+        float rf[8];
+        unpack_bf16x8(rr, rf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rf[e];
+      }
+    }
+    if (p.res2) {
+      const u32x4 rr = *(const u32x4*)(p.res2 + ((size_t)m * p.ldr2 + n) * 2);
+      float rf[8];
+      unpack_bf16x8(rr, rf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rf[e];
+    }
+    if (flags & V3A_GEMM_RELU_OUT) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    const size_t mo = p.orow_group > 0 ? (size_t)m + (size_t)(m / p.orow_group) * p.orow_skip + p.orow_off : (size_t)m;
+    if (flags & V3A_GEMM_OUT_F32) {
+      float* cp = (float*)p.C + mo * p.ldc + n;
+      f32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
+      *(f32x4*)cp = o0;
+      *(f32x4*)(cp + 4) = o1;
+    } else {
+      *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = pack_bf16x8(v);
+    }
+  }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this group's reads returned before the next group overwrites the region
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // STG = 0: tiles arrive by LDS-DMA (global_load_lds) into an NS-deep ring.
 // STG = 1: tiles are staged through registers (global_load_dwordx4 -> ds_write_b128, 2 LDS buffers): the loads of slab t+2
 //          are issued, and the slab t+1 registers written to LDS, BETWEEN the MFMA groups of slab t.  An LDS-DMA instruction
@@ -105,9 +240,7 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_
   // tiles instead of 1-2 A panels + every W panel (FFN1: 535 MB -> ~260 MB of L2 fills per launch).
   constexpr int GM = (OCC * 32 * BN / BM >= 36) ? 8 : 4;  // ~sqrt(tiles in flight per XCD x BN/BM): squarest in-flight patch
   int tm, tn;
-  if (p.flags & (1 << 27)) {  // A/B switch: plain row-major order
-    tm = t / tilesN; tn = t % tilesN;
-  } else {
+  {
     const int gsz = GM * tilesN, gid = t / gsz, first = gid * GM;
     const int gm = min(tilesM - first, GM), r = t - gid * gsz;
     tm = first + r % gm; tn = r / gm;
@@ -325,146 +458,215 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_
     __builtin_amdgcn_s_barrier();  // all fragment reads retired before the ring is reused by the epilogue
   }
 
-  if (p.flags & (1 << 29)) {  // DEBUG/profiling only: skip the epilogue (accumulators kept live by a never-taken store)
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NTL; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
-    if (sum == 123456.789f) ((float*)p.C)[tid] = sum;
-    return;
+  gemm_epilogue<MT, NTL>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+}
+
+// =====================================================================================================================
+// Ping-pong ("8-phase") main loop: 8 waves, one workgroup per CU, 256 x (64*NP) output tile (or its transpose), BK = 64.
+//
+// The tile's operands are an R side (256 rows: 4 waves x 64 rows, fragments RESIDENT in registers for a whole K tile) and an
+// S side (64*NP rows: 2 waves x NP blocks of 32 rows, STREAMED one block per phase).  A K tile is NP phases; in phase c a wave
+// multiplies its two resident R blocks with S block c: 2 x 4 k-steps = 8 v_mfma_f32_32x32x16_bf16 (256 matrix-pipe cycles).
+// The two waves that share a SIMD (wave w and w+4) sit in different groups; group 1 runs one barrier interval behind group 0,
+// so on every SIMD one wave is in its MFMA section while its partner reads fragments from LDS and issues the LDS-DMA refill:
+//      interval 2n   : G0 load(n)   | G1 mfma(n-1)
+//      interval 2n+1 : G0 mfma(n)   | G1 load(n)
+// K tiles live in two LDS buffers.  Per wave a tile is J = (256 + 64 NP)/64 DMA instructions of 8 rows x 128 B, issued as a
+// stream ordered by first use  [S0, R0..R3, S1, .., S(NP-1)]  cut into NP chunks; chunk q is issued in the load section of phase
+// q - LEAD, i.e. LEAD phases (LEAD x 512 cycles) before the phase that first reads it, and stays in flight across barriers
+// (counted s_waitcnt vmcnt, raw s_barrier; never drained in the steady state).
+//   RAW: every wave waits for ITS share of the data of phase n+1 inside interval 2n+1 (G0: end of mfma(n), G1: end of load(n));
+//        barrier B(2n+1) then orders all shares before G0's load(n+1) (interval 2n+2) and G1's (2n+3).
+//   WAR: a block last read in phase m has been read by G0 in interval 2m (returned by its lgkmcnt(0) in 2m+1) and by G1 in
+//        2m+1 (returned in 2m+2), so its LDS may be refilled from G0's load(m+2) / G1's load(m+1) on.  R is read in phase 0,
+//        S_c in phase c, and the refill of tile t+2 into tile t's buffer honours  issue phase >= m + 2  iff  LEAD <= 2 NP - 2.
+// Accumulation order per output element is the same ascending-k chain of 32x32x16 MFMAs as gemm_nt_kernel: bit-identical results.
+template <int NP>
+struct PPCfg {
+  static constexpr int RROWS = 256, SROWS = 64 * NP, RB = 128;
+  static constexpr int STAGE = (RROWS + SROWS) * RB;
+  static constexpr int J = (RROWS + SROWS) / 64;                  // DMA instructions per wave per K tile (7 / 8)
+  static constexpr int cnt(int c) { return NP == 3 ? (c == 0 ? 3 : 2) : 2; }   // instructions in chunk c
+  static constexpr int cum(int k) { int s = 0; for (int i = 0; i < k; ++i) s += cnt(i); return s; }
+  static constexpr int need(int c) { return 5 + c; }              // leading instructions of a tile that phase c reads
+  // vmcnt to wait for before phase c of a tile with `rem` tiles left (incl. itself; >= 3 = steady state), waited right after
+  // chunk (phase - 1 + LEAD) was issued
+  static constexpr int allowed(int c, int rem, int LEAD) {
+    const int x = c - 1 + LEAD;
+    const int steady = J * (x / NP) + cum(x % NP + 1) - need(c);
+    const int tail = J * rem - need(c);
+    return (rem >= 3 || steady < tail) ? steady : tail;
   }
-  // ---- epilogue: per 32-row group of the wave tile:
-  //   phase 1: acc + bias -> bf16 -> this wave's private LDS region (32 rows x WTN)
-  //   phase 2: whole-row re-read, fused elementwise, 16-byte coalesced stores
-  char* reg = smem + wave * (32 * PITCH);
-  const int mw0 = m0 + wm * WTM, nw = n0 + wn * WTN;
-  const bool bias_row = (p.flags & V3A_GEMM_BIAS_ROW) != 0;
-  constexpr int CH = WTN / 8;
-  constexpr int ITERS = 32 * CH / 64;
-  static_assert((32 * CH) % 64 == 0, "epilogue chunking");
-  const int act = p.act, flags = p.flags;
+  static constexpr int EPI_BYTES = 8 * 32 * (128 * 2 + 8);
+  static constexpr int LDS_BYTES = 2 * STAGE;
+  static_assert(J == cum(NP), "chunking");
+  static_assert(LDS_BYTES >= EPI_BYTES, "epilogue parks in the ring");
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int NP, bool RA, int LEAD>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
+  using T = PPCfg<NP>;
+  constexpr int RB = T::RB, STAGE = T::STAGE, J = T::J;
+  constexpr int BM = RA ? 256 : 64 * NP, BN = RA ? 64 * NP : 256;
+  constexpr int MT = RA ? 2 : NP, NTL = RA ? NP : 2;
+  static_assert(LEAD >= 1 && LEAD <= 2 * NP - 2, "refill would overtake the readers of the buffer");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;          // waves w and w+4 share a SIMD: opposite groups
+  const int wr = wave & 3, ws = wave >> 2;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
+  const int tl = xcd_remap(blockIdx.x, tilesM * tilesN);
+  constexpr int GM = RA ? 4 : 8;      // grouped raster: near-square patch of tiles in flight per XCD
+  int tm, tn;
+  {
+    const int gsz = GM * tilesN, gid = tl / gsz, first = gid * GM;
+    const int gm = min(tilesM - first, GM), r = tl - gid * gsz;
+    tm = first + r % gm; tn = r / gm;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // R / S side views of the two operands
+  const char* Rp = RA ? p.A : p.B;
+  const char* Sp = RA ? p.B : p.A;
+  const int ldR = RA ? p.lda : p.ldb, ldS = RA ? p.ldb : p.lda;
+  const int r0 = RA ? m0 : n0, s0 = RA ? n0 : m0;
+  const int Rn = RA ? p.M : p.N, Sn = RA ? p.N : p.M;
+
+  // ---- per-lane DMA sources in stream order; LDS image row-major 128-B rows, chunk' = chunk ^ ((row >> 1) & 7) ----
+  const char* gp[J];
+  int ldst[J];  // wave-uniform LDS byte offset inside a stage
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int mw = mw0 + i * 32;
-    {
-      const int ml = l31;
-      float brow = 0.f;
-      if (p.bias && bias_row) {
-        int m = mw + ml;
-        brow = p.bias[m < p.M ? m : p.M - 1];
+  for (int j = 0; j < J; ++j) {
+    const bool isR = (j >= 1 && j <= 4);
+    int row;  // row inside the R or S region (multiple of 8 per instruction)
+    if (isR) row = ((j - 1) * 8 + wave) * 8;
+    else row = (wave >> 2) * (32 * NP) + (j == 0 ? 0 : j - 4) * 32 + (wave & 3) * 8;
+    ldst[j] = (isR ? 0 : T::RROWS * RB) + row * RB;
+    const int rl = row + (lane >> 3);
+    const int c = (lane & 7) ^ ((rl >> 1) & 7);
+    int grow = (isR ? r0 : s0) + rl;
+    const int lim = isR ? Rn : Sn;
+    grow = grow < lim ? grow : lim - 1;
+    gp[j] = (isR ? Rp : Sp) + ((size_t)grow * (isR ? ldR : ldS)) * 2 + c * 16;
+  }
+  // chunk cc of the next not-yet-issued tile -> stage `buf`
+  auto issue = [&](auto cc_tag, int buf) {
+    constexpr int cc = decltype(cc_tag)::value;
+#pragma unroll
+    for (int j = T::cum(cc); j < T::cum(cc + 1); ++j) {
+      glds16(gp[j], smem + buf * STAGE + ldst[j]);
+      gp[j] += RB;
+    }
+  };
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int sw = (l31 >> 1) & 7;
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * RB + (((2 * ks + hi) ^ sw) << 4);
+  const int roff = (wr * 64) * RB, soff = (T::RROWS + ws * 32 * NP) * RB;
+
+  const int nk = p.K / 64;
+  // ---- prologue: chunks 0 .. LEAD-1 ----
+  {
+    auto pro = [&](auto q_tag) {
+      constexpr int q = decltype(q_tag)::value;
+      if (q / NP < nk) issue(std::integral_constant<int, q % NP>{}, (q / NP) & 1);
+    };
+    pro(std::integral_constant<int, 0>{});
+    if constexpr (LEAD > 1) pro(std::integral_constant<int, 1>{});
+    if constexpr (LEAD > 2) pro(std::integral_constant<int, 2>{});
+    if constexpr (LEAD > 3) pro(std::integral_constant<int, 3>{});
+    if constexpr (LEAD > 4) pro(std::integral_constant<int, 4>{});
+    if constexpr (LEAD > 5) pro(std::integral_constant<int, 5>{});
+    if (nk >= 3) wait_vmcnt<T::allowed(0, 3, LEAD)>();
+    else if (nk == 2) wait_vmcnt<T::allowed(0, 2, LEAD)>();
+    else wait_vmcnt<T::allowed(0, 1, LEAD)>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 now runs one interval behind group 0
+  }
+
+  bf16x8 rf[2][4], sf[4];
+  // counted wait for the data of phase nc of a tile with nrem tiles left (including itself); exact in the tail, where fewer
+  // instructions than the steady-state count are outstanding behind the needed ones
+  auto wait_phase = [&](auto nc_tag, int nrem) {
+    constexpr int nc = decltype(nc_tag)::value;
+    constexpr int a3 = T::allowed(nc, 3, LEAD), a2 = T::allowed(nc, 2, LEAD), a1 = T::allowed(nc, 1, LEAD);
+    if (nrem >= 3 || (a2 == a3 && nrem == 2)) wait_vmcnt<a3>();
+    else if (nrem == 2) wait_vmcnt<a2>();
+    else if (nrem == 1) wait_vmcnt<a1>();
+  };
+  // one K tile.  BUF = its stage, rem = tiles left including this one (wave-uniform).
+  auto tile = [&](auto buf_tag, const int rem) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const char* sR = smem + BUF * STAGE + roff;
+    const char* sS = smem + BUF * STAGE + soff;
+    auto phase = [&](auto c_tag) {
+      constexpr int c = decltype(c_tag)::value;
+      // ---------------- load section ----------------
+      if constexpr (c == 0) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) rf[b][ks] = *(const bf16x8*)(sR + b * 32 * RB + koff[ks]);
       }
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) {
+      for (int ks = 0; ks < 4; ++ks) sf[ks] = *(const bf16x8*)(sS + c * 32 * RB + koff[ks]);
+      // chunk (c + LEAD) of the stream belongs to tile t + (c + LEAD) / NP
+      if ((c + LEAD) / NP < rem) issue(std::integral_constant<int, (c + LEAD) % NP>{}, BUF ^ (((c + LEAD) / NP) & 1));
+      // data of the NEXT phase
+      constexpr int nc = c + 1 < NP ? c + 1 : 0;
+      const int nrem = c + 1 < NP ? rem : rem - 1;
+      if (grp == 1) wait_phase(std::integral_constant<int, nc>{}, nrem);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---------------- MFMA section ----------------
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = j * 32 + g * 8 + hi * 4;
-          float v[4];
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
-          if (p.bias) {
-            if (bias_row) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += brow;
-            } else {
-              const int n = nw + nl;
-              if (n + 3 < p.N) {
-                const f32x4 bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bv[e];
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (n + e < p.N) v[e] += p.bias[n + e];
-              }
-            }
-          }
-          u32x2 pk;
-          pk[0] = pack_bf16x2(v[0], v[1]);
-          pk[1] = pack_bf16x2(v[2], v[3]);
-          *(u32x2*)(reg + ml * PITCH + nl * 2) = pk;
+        for (int b = 0; b < 2; ++b) {
+          if constexpr (RA) acc[b][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[ks], rf[b][ks], acc[b][c], 0, 0, 0);
+          else acc[c][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[b][ks], sf[ks], acc[c][b], 0, 0, 0);
         }
-      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp == 0) wait_phase(std::integral_constant<int, nc>{}, nrem);
+      __builtin_amdgcn_s_barrier();
+    };
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    if constexpr (NP > 3) phase(std::integral_constant<int, 3>{});
+  };
+  {
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      tile(std::integral_constant<int, 0>{}, nk - t);
+      tile(std::integral_constant<int, 1>{}, nk - t - 1);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
-    for (int it = 0; it < ITERS; ++it) {
-    const int idx = it * 64 + lane;
-    const int ml = idx / CH, ch = idx % CH;
-    const int m = mw + ml, n = nw + ch * 8;
-    const u32x2 lo = *(const u32x2*)(reg + ml * PITCH + ch * 16);
-    const u32x2 hi2 = *(const u32x2*)(reg + ml * PITCH + ch * 16 + 8);
-    if (m >= p.M || n >= p.N) continue;
-    if (p.flags & (1 << 30)) continue;  // DEBUG/profiling only: phase 2 without global traffic
-    u32x4 raw;
-    raw[0] = lo[0]; raw[1] = lo[1]; raw[2] = hi2[0]; raw[3] = hi2[1];
-    float v[8];
-    unpack_bf16x8(raw, v);
-    if (act != V3A_ACT_NONE) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = v[e];
-        if (act == V3A_ACT_GELU_TANH) x = gelu_tanh(x);
-        else if (act == V3A_ACT_GELU_ERF) x = gelu_erf(x);
-        else if (act == V3A_ACT_SILU) x = silu(x);
-        else x = fmaxf(x, 0.f);
-        v[e] = round_bf16(x);
-      }
-    }
-    if (p.scale) {
-      const float* sp = p.scale + ((flags & V3A_GEMM_SCALE_PER_BATCH) ? (size_t)(m / p.rpb) * p.sstride : 0) + n;
-      const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] *= s0[e]; v[4 + e] *= s1[e]; }
-      if (flags & V3A_GEMM_ROUND_AFTER_SCALE) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e]);
-      }
-    }
-    if (p.res) {
-      const int mr = p.res_mod > 0 ? m % p.res_mod : m;
-      if (flags & V3A_GEMM_RES_F32) {
-        const float* rp = (const float*)p.res + (size_t)mr * p.ldr + n;
-        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-      } else {
-        const u32x4 rr = *(const u32x4*)(p.res + ((size_t)mr * p.ldr + n) * 2);
-        float rf[8];
-        unpack_bf16x8(rr, rf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rf[e];
-      }
-    }
-    if (p.res2) {
-      const u32x4 rr = *(const u32x4*)(p.res2 + ((size_t)m * p.ldr2 + n) * 2);
-      float rf[8];
-      unpack_bf16x8(rr, rf);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += rf[e];
-    }
-    if (flags & V3A_GEMM_RELU_OUT) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-    const size_t mo = p.orow_group > 0 ? (size_t)m + (size_t)(m / p.orow_group) * p.orow_skip + p.orow_off : (size_t)m;
-    if (flags & V3A_GEMM_OUT_F32) {
-      float* cp = (float*)p.C + mo * p.ldc + n;
-      f32x4 o0, o1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
-      *(f32x4*)cp = o0;
-      *(f32x4*)(cp + 4) = o1;
-    } else {
-      *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = pack_bf16x8(v);
-    }
+    if (t < nk) tile(std::integral_constant<int, 0>{}, 1);
   }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this group's reads returned before the next group overwrites the region
-    __builtin_amdgcn_wave_barrier();
-  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align the groups: every fragment read has returned, no DMA in flight
+
+  if constexpr (RA) gemm_epilogue<MT, NTL>(p, acc, smem, wave, lane, m0 + wr * 64, n0 + ws * 32 * NP);
+  else gemm_epilogue<MT, NTL>(p, acc, smem, wave, lane, m0 + ws * 32 * NP, n0 + wr * 64);
 }
 
 typedef void (*gemm_fn)(const GemmP);
@@ -488,6 +690,10 @@ constexpr gemm_fn conv_kernel_or_null() {
   { #BM "x" #BN "_w" #WM "x" #WN "_k" #BK "s" #NS "_occ" #OCC, BM, BN, TileCfg<BM, BN, WM, WN, BK, NS>::NTHR, \
     TileCfg<BM, BN, WM, WN, BK, NS>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, false, 0, OCC>, nullptr }
 
+#define PP_ENTRY(NP, RA, LEAD)                                                                      \
+  { "pp_np" #NP "_ra" #RA "_l" #LEAD, (RA) ? 256 : 64 * NP, (RA) ? 64 * NP : 256, 512, PPCfg<NP>::LDS_BYTES, \
+    (gemm_fn)gemm_pp_kernel<NP, RA, LEAD>, nullptr }
+
 const TileEntry kTiles[] = {
     TILE_ENTRY(256, 192, 4, 2, 64, 2),  // 0: N % 192 == 0 shapes (d=1536): 8192x1536 -> exactly 256 tiles
     TILE_ENTRY(192, 256, 2, 4, 64, 2),  // 1: transposed role of 0 (V^T = Wv . X^T)
@@ -501,6 +707,12 @@ const TileEntry kTiles[] = {
     TILE_ENTRY_OCC(128, 192, 2, 2, 64, 2, 2),  // 8: 80 KiB, 4 waves, 2 per CU
     TILE_ENTRY_OCC(192, 128, 2, 2, 32, 2, 4),  // 9
     TILE_ENTRY_OCC(192, 256, 2, 4, 32, 2, 2),  // 10: transposed role of 6
+    // ping-pong main loop (gemm_pp_kernel), one 8-wave workgroup per CU
+    PP_ENTRY(3, true, 4),    // 11: 256x192
+    PP_ENTRY(4, true, 6),    // 12: 256x256
+    PP_ENTRY(3, false, 4),   // 13: 192x256
+    PP_ENTRY(4, true, 4),    // 14: 256x256, shorter DMA lead (tuning)
+    PP_ENTRY(3, true, 3),    // 15: 256x192, shorter DMA lead (tuning)
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 int g_attr_lds[kNumTiles][2] = {};
@@ -544,6 +756,9 @@ int launch(const GemmP& p, int ti, bool conv, void* stream) {
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
+constexpr int kKnownFlags = V3A_GEMM_BIAS_ROW | V3A_GEMM_SCALE_PER_BATCH | V3A_GEMM_ROUND_AFTER_SCALE | V3A_GEMM_RES_F32 |
+                            V3A_GEMM_OUT_F32 | V3A_GEMM_NO_ROUND_ACC | V3A_GEMM_RELU_OUT;
+
 }  // namespace
 
 extern "C" int v3a_gemm_num_tiles(void) { return kNumTiles; }
@@ -556,6 +771,7 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   if (a->K % 64 || a->lda % 8 || a->ldb % 8 || a->ldc % 8 || a->N % 8) return V3A_ERR_SHAPE;
   if (a->residual && (a->ldr % 8)) return V3A_ERR_SHAPE;
   if ((a->flags & V3A_GEMM_SCALE_PER_BATCH) && a->scale && a->rows_per_batch <= 0) return V3A_ERR_ARG;
+  if (a->flags & ~kKnownFlags) return V3A_ERR_ARG;          // a stray bit must not silently change behaviour
   if (a->flags & V3A_GEMM_NO_ROUND_ACC) return V3A_ERR_ARG;  // not implemented: accumulators are parked as bf16
   GemmP p = {};
   p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C;
@@ -564,7 +780,6 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldr = a->ldr;
   p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : 1; p.sstride = a->scale_stride;
   p.act = a->act; p.flags = a->flags;
-  { static const bool rowmajor = getenv("V3A_GEMM_ROWMAJOR") != nullptr; if (rowmajor) p.flags |= 1 << 27; }  // A/B switch
   p.res2 = (const char*)a->residual2; p.ldr2 = a->ldr2; p.res_mod = a->res_row_mod;
   p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
   if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
@@ -578,6 +793,7 @@ extern "C" int v3a_conv_bf16(const v3a_conv_args* a, void* stream) {
   if (a->Cin % 8 || a->Cout % 8 || a->Kpad % 64 || a->ldy % 8 || a->Kpad / 8 > 4096) return V3A_ERR_SHAPE;
   if (a->residual && (a->ldr % 8)) return V3A_ERR_SHAPE;
   if ((long)a->oT * a->oH * a->oW > 0x7fffffffL) return V3A_ERR_SHAPE;
+  if (a->flags & ~kKnownFlags) return V3A_ERR_ARG;
   if (a->flags & (V3A_GEMM_BIAS_ROW | V3A_GEMM_NO_ROUND_ACC)) return V3A_ERR_ARG;
   GemmP p = {};
   p.A = (const char*)a->x; p.B = (const char*)a->w; p.C = (char*)a->y;
@@ -586,7 +802,6 @@ extern "C" int v3a_conv_bf16(const v3a_conv_args* a, void* stream) {
   p.lda = 0; p.ldb = a->Kpad; p.ldc = a->ldy; p.ldr = a->ldr;
   p.rpb = 1; p.sstride = 0;
   p.act = a->act; p.flags = a->flags & ~V3A_GEMM_SCALE_PER_BATCH;
-  { static const bool rowmajor = getenv("V3A_GEMM_ROWMAJOR") != nullptr; if (rowmajor) p.flags |= 1 << 27; }  // A/B switch
   p.ktab = a->ktab;
   p.cT = a->T; p.cH = a->H; p.cW = a->W; p.cCin = a->Cin;
   p.oH = a->oH; p.oW = a->oW;
