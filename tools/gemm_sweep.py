@@ -47,6 +47,10 @@ if __name__ == "__main__":
     shapes = ((8192, 1536, 1536, True), (8192, 3072, 1536, False), (8192, 8960, 1536, False), (8192, 1536, 8960, True),
               (1536, 8192, 1536, False), (4096, 1536, 1536, True), (8192, 5120, 5120, False), (8192, 13824, 5120, False),
               (8192, 8192, 8192, False))
+    if len(sys.argv) > 2 and "x" in sys.argv[2]:   # custom shapes: MxNxK[r];MxNxK...
+        shapes = [tuple(int(v) for v in sh.rstrip("r").split("x")) + (sh.endswith("r"),) for sh in sys.argv[2].split(";")]
+    elif len(sys.argv) > 2:
+        shapes = [shapes[int(i)] for i in sys.argv[2].split(",")]
     for (M, N, K, res) in shapes:
         row, ref = {}, None
         for tile in tiles:

@@ -15,7 +15,7 @@ CSRC = HERE / "csrc"
 OBJ = CSRC / "build"
 LIB = HERE / "libvist3a_hip.so"
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"] + os.environ.get("V3A_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:

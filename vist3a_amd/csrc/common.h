@@ -53,17 +53,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)gsrc, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
-// GELU, tanh approximation (torch F.gelu(approximate="tanh")).
+// GELU, tanh approximation (torch F.gelu(approximate="tanh")):  0.5 x (1 + tanh(u)) = x * sigmoid(2u) = x / (1 + 2^(-2u log2 e)),
+// u = sqrt(2/pi) (x + 0.044715 x^3).  One v_exp_f32 + one v_rcp_f32 (1 ulp) per element instead of an IEEE division: the value
+// is rounded to bf16 right after, eight mantissa bits above the approximation error.  Saturates correctly (2^inf -> rcp(inf) = 0).
 __device__ __forceinline__ float gelu_tanh(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  // tanh(u) = 1 - 2/(exp(2u)+1); safe for large |u|
-  float e = __expf(2.0f * u);
-  float t = 1.0f - 2.0f / (e + 1.0f);
-  return 0.5f * x * (1.0f + t);
+  const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c1 = c0 * 0.044715f;
+  const float t = x * (c0 + c1 * x * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -77,136 +77,241 @@ struct TileCfg {
 
 // Epilogue shared by every main loop: the wave owns an (MT*32) x (NTL*32) output tile whose 32x32 blocks sit in acc[i][j] in
 // D^T orientation (lane (l31, hi) holds rows m = l31, 4 consecutive columns per accumulator quad).  Per 32-row group:
-//   phase 1: acc + bias -> bf16 -> this wave's private LDS region (32 rows x WTN)
+//   phase 1: acc (bias already added by gemm_add_bias) -> bf16 -> this wave's private
+//            LDS region (32 rows x WTN)
 //   phase 2: whole-row re-read, fused elementwise, 16-byte coalesced stores
-template <int MT, int NTL>
+// The epilogue is latency-, not bandwidth-bound when written naively (a dependent global load per quad / per row chunk:
+// measured 7 us of a 38 us FFN1 tile), so every global load is issued ahead of its use: the bias in one batch before phase 1, and
+// residual / gate loads in batches of PFB row chunks, with EARLY the first batch of a group BEFORE phase 1 so that its latency
+// hides under the convert-and-park work (the two-workgroups-per-CU tiles have no registers for that).
+template <int MT, int NTL, int PFB, bool EARLY, int DBG = 0, bool BIAS_P1 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane,
                                               int mw0, int nw) {
   constexpr int WTN = NTL * 32, PITCH = WTN * 2 + 8;
+  if constexpr (DBG & 2) {   // development ablation: no epilogue at all (accumulators kept live)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) { f32x16 t = acc[i][j]; asm volatile("" : "+v"(t)); acc[i][j] = t; }
+    return;
+  }
   const int hi = lane >> 5, l31 = lane & 31;
   char* reg = smem + wave * (32 * PITCH);
-  const bool bias_row = (p.flags & V3A_GEMM_BIAS_ROW) != 0;
   constexpr int CH = WTN / 8;
   constexpr int ITERS = 32 * CH / 64;
   static_assert((32 * CH) % 64 == 0, "epilogue chunking");
+  constexpr int PB = PFB > 0 ? PFB : 1;   // PFB = 0: loads issued inside each row chunk (register-capped two-per-CU tiles)
+  static_assert(ITERS % PB == 0, "prefetch batch");
   const int act = p.act, flags = p.flags;
+  const bool res_f32 = (flags & V3A_GEMM_RES_F32) != 0;
+
+  // prefetched operands of one row chunk (8 consecutive columns of one output row)
+  u32x4 pr0[PB], pr1[PB];   // residual: bf16 x8 in pr0, or f32 x8 in pr0|pr1
+  f32x4 ps0[PB], ps1[PB];   // scale
+  auto coords = [&](int mw, int it, int& m, int& n, int& ml, int& ch) {
+    const int idx = it * 64 + lane;
+    ml = idx / CH; ch = idx % CH;
+    m = mw + ml; n = nw + ch * 8;
+  };
+  auto fetch = [&](int mw, int it, int s) {
+    int m, n, ml, ch;
+    coords(mw, it, m, n, ml, ch);
+    if (m >= p.M || n >= p.N) return;
+    if (p.scale) {
+      const float* sp = p.scale + ((flags & V3A_GEMM_SCALE_PER_BATCH) ? (size_t)(m / p.rpb) * p.sstride : 0) + n;
+      ps0[s] = *(const f32x4*)sp; ps1[s] = *(const f32x4*)(sp + 4);
+    }
+    if (p.res) {
+      const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+      if (res_f32) {
+        const float* rp = (const float*)p.res + (size_t)mr * p.ldr + n;
+        pr0[s] = *(const u32x4*)rp; pr1[s] = *(const u32x4*)(rp + 4);
+      } else {
+        pr0[s] = *(const u32x4*)(p.res + ((size_t)mr * p.ldr + n) * 2);
+      }
+    }
+  };
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int mw = mw0 + i * 32;
-    {
-      const int ml = l31;
-      float brow = 0.f;
-      if (p.bias && bias_row) {
-        int m = mw + ml;
-        brow = p.bias[m < p.M ? m : p.M - 1];
-      }
+    if constexpr (EARLY) {
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) {
+      for (int s = 0; s < PB; ++s) fetch(mw, s, s);
+    }
+    float brow = 0.f;
+    const bool bias_row = (flags & V3A_GEMM_BIAS_ROW) != 0;
+    if (BIAS_P1 && p.bias && bias_row) {
+      const int m = mw + l31;
+      brow = p.bias[m < p.M ? m : p.M - 1];
+    }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nl = j * 32 + g * 8 + hi * 4;
-          float v[4];
+    for (int j = 0; j < NTL; ++j) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
-          if (p.bias) {
-            if (bias_row) {
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += brow;
-            } else {
-              const int n = nw + nl;
-              if (n + 3 < p.N) {
-                const f32x4 bv = *(const f32x4*)(p.bias + n);
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
+        if (BIAS_P1 && p.bias) {   // register-capped tiles: bias loaded per quad (no room for gemm_add_bias's batch)
+          const int n = nw + j * 32 + g * 8 + hi * 4;
+          if (bias_row) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bv[e];
-              } else {
+            for (int e = 0; e < 4; ++e) v[e] += brow;
+          } else if (n + 3 < p.N) {
+            const f32x4 bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (n + e < p.N) v[e] += p.bias[n + e];
-              }
-            }
+            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) v[e] += p.bias[n + e];
           }
-          u32x2 pk;
-          pk[0] = pack_bf16x2(v[0], v[1]);
-          pk[1] = pack_bf16x2(v[2], v[3]);
-          *(u32x2*)(reg + ml * PITCH + nl * 2) = pk;
         }
+        u32x2 pk;
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
+        *(u32x2*)(reg + l31 * PITCH + (j * 32 + g * 8 + hi * 4) * 2) = pk;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
-    for (int it = 0; it < ITERS; ++it) {
-    const int idx = it * 64 + lane;
-    const int ml = idx / CH, ch = idx % CH;
-    const int m = mw + ml, n = nw + ch * 8;
-    const u32x2 lo = *(const u32x2*)(reg + ml * PITCH + ch * 16);
-    const u32x2 hi2 = *(const u32x2*)(reg + ml * PITCH + ch * 16 + 8);
-    if (m >= p.M || n >= p.N) continue;
-    u32x4 raw;
-    raw[0] = lo[0]; raw[1] = lo[1]; raw[2] = hi2[0]; raw[3] = hi2[1];
-    float v[8];
-    unpack_bf16x8(raw, v);
-    if (act != V3A_ACT_NONE) {
+#pragma unroll(PFB > 0 ? ITERS : 2)
+    for (int it0 = 0; it0 < ITERS; it0 += PB) {
+      if (PFB > 0 && (!EARLY || it0 > 0)) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = v[e];
-        if (act == V3A_ACT_GELU_TANH) x = gelu_tanh(x);
-        else if (act == V3A_ACT_GELU_ERF) x = gelu_erf(x);
-        else if (act == V3A_ACT_SILU) x = silu(x);
-        else x = fmaxf(x, 0.f);
-        v[e] = round_bf16(x);
+        for (int s = 0; s < PB; ++s) fetch(mw, it0 + s, s);
+      }
+#pragma unroll
+      for (int s = 0; s < PB; ++s) {
+        int m, n, ml, ch;
+        coords(mw, it0 + s, m, n, ml, ch);
+        const u32x2 lo = *(const u32x2*)(reg + ml * PITCH + ch * 16);
+        const u32x2 hi2 = *(const u32x2*)(reg + ml * PITCH + ch * 16 + 8);
+        if (m >= p.M || n >= p.N) continue;
+        if constexpr (PFB == 0) fetch(mw, it0, 0);
+        u32x4 raw;
+        raw[0] = lo[0]; raw[1] = lo[1]; raw[2] = hi2[0]; raw[3] = hi2[1];
+        float v[8];
+        unpack_bf16x8(raw, v);
+        if (act != V3A_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if (act == V3A_ACT_GELU_TANH) x = gelu_tanh(x);
+            else if (act == V3A_ACT_GELU_ERF) x = gelu_erf(x);
+            else if (act == V3A_ACT_SILU) x = silu(x);
+            else x = fmaxf(x, 0.f);
+            v[e] = round_bf16(x);
+          }
+        }
+        if (p.scale) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] *= ps0[s][e]; v[4 + e] *= ps1[s][e]; }
+          if (flags & V3A_GEMM_ROUND_AFTER_SCALE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e]);
+          }
+        }
+        if (p.res) {
+          if (res_f32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(pr0[s][e]); v[4 + e] += __uint_as_float(pr1[s][e]); }
+          } else {
+            float rf[8];
+            unpack_bf16x8(pr0[s], rf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rf[e];
+          }
+        }
+        if (p.res2) {
+          const u32x4 rr = *(const u32x4*)(p.res2 + ((size_t)m * p.ldr2 + n) * 2);
+          float rf[8];
+          unpack_bf16x8(rr, rf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rf[e];
+        }
+        if (flags & V3A_GEMM_RELU_OUT) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const size_t mo = p.orow_group > 0 ? (size_t)m + (size_t)(m / p.orow_group) * p.orow_skip + p.orow_off : (size_t)m;
+        if constexpr (DBG & 1) {   // development ablation: everything but the global stores
+          if (v[0] == 123456.789f) *(float*)p.C = v[1];
+          continue;
+        }
+        if (flags & V3A_GEMM_OUT_F32) {
+          float* cp = (float*)p.C + mo * p.ldc + n;
+          f32x4 o0, o1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
+          *(f32x4*)cp = o0;
+          *(f32x4*)(cp + 4) = o1;
+        } else {
+          *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = pack_bf16x8(v);
+        }
       }
     }
-    if (p.scale) {
-      const float* sp = p.scale + ((flags & V3A_GEMM_SCALE_PER_BATCH) ? (size_t)(m / p.rpb) * p.sstride : 0) + n;
-      const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] *= s0[e]; v[4 + e] *= s1[e]; }
-      if (flags & V3A_GEMM_ROUND_AFTER_SCALE) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e]);
-      }
-    }
-    if (p.res) {
-      const int mr = p.res_mod > 0 ? m % p.res_mod : m;
-      if (flags & V3A_GEMM_RES_F32) {
-        const float* rp = (const float*)p.res + (size_t)mr * p.ldr + n;
-        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-      } else {
-        const u32x4 rr = *(const u32x4*)(p.res + ((size_t)mr * p.ldr + n) * 2);
-        float rf[8];
-        unpack_bf16x8(rr, rf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rf[e];
-      }
-    }
-    if (p.res2) {
-      const u32x4 rr = *(const u32x4*)(p.res2 + ((size_t)m * p.ldr2 + n) * 2);
-      float rf[8];
-      unpack_bf16x8(rr, rf);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += rf[e];
-    }
-    if (flags & V3A_GEMM_RELU_OUT) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-    const size_t mo = p.orow_group > 0 ? (size_t)m + (size_t)(m / p.orow_group) * p.orow_skip + p.orow_off : (size_t)m;
-    if (flags & V3A_GEMM_OUT_F32) {
-      float* cp = (float*)p.C + mo * p.ldc + n;
-      f32x4 o0, o1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
-      *(f32x4*)cp = o0;
-      *(f32x4*)(cp + 4) = o1;
-    } else {
-      *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = pack_bf16x8(v);
-    }
-  }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this group's reads returned before the next group overwrites the region
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// acc += bias (fp32), ahead of the epilogue: all bias loads of the wave tile are issued together (one exposed latency instead of
+// one per accumulator quad) and only once, since the column bias is the same for every 32-row group.
+template <int MT, int NTL, bool LIGHT = false>   // LIGHT: one 32-column block at a time (register-capped two-per-CU tiles)
+__device__ __forceinline__ void gemm_add_bias(const GemmP& p, f32x16 (&acc)[MT][NTL], int lane, int mw0, int nw) {
+  const int hi = lane >> 5, l31 = lane & 31;
+  if (!p.bias) return;
+  if (p.flags & V3A_GEMM_BIAS_ROW) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = mw0 + i * 32 + l31;
+      const float b = p.bias[m < p.M ? m : p.M - 1];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += b;
+    }
+  } else if constexpr (LIGHT) {
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      f32x4 bq[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nw + j * 32 + g * 8 + hi * 4;
+        if (n + 3 < p.N) bq[g] = *(const f32x4*)(p.bias + n);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bq[g][e] = n + e < p.N ? p.bias[n + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][g * 4 + e] += bq[g][e];
+    }
+  } else {
+    f32x4 bq[NTL][4];
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nw + j * 32 + g * 8 + hi * 4;
+        if (n + 3 < p.N) bq[j][g] = *(const f32x4*)(p.bias + n);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bq[j][g][e] = n + e < p.N ? p.bias[n + e] : 0.f;
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][g * 4 + e] += bq[j][g][e];
   }
 }
 
@@ -458,7 +563,8 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_
     __builtin_amdgcn_s_barrier();  // all fragment reads retired before the ring is reused by the epilogue
   }
 
-  gemm_epilogue<MT, NTL>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+  if constexpr (OCC == 1) gemm_add_bias<MT, NTL>(p, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
+  gemm_epilogue<MT, NTL, (OCC > 1 ? 0 : (NTL < 3 ? 2 : NTL)), (OCC == 1 && MT * NTL < 8), 0, (OCC > 1)>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
 // =====================================================================================================================
@@ -467,19 +573,21 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_
 // The tile's operands are an R side (256 rows: 4 waves x 64 rows, fragments RESIDENT in registers for a whole K tile) and an
 // S side (64*NP rows: 2 waves x NP blocks of 32 rows, STREAMED one block per phase).  A K tile is NP phases; in phase c a wave
 // multiplies its two resident R blocks with S block c: 2 x 4 k-steps = 8 v_mfma_f32_32x32x16_bf16 (256 matrix-pipe cycles).
-// The two waves that share a SIMD (wave w and w+4) sit in different groups; group 1 runs one barrier interval behind group 0,
-// so on every SIMD one wave is in its MFMA section while its partner reads fragments from LDS and issues the LDS-DMA refill:
-//      interval 2n   : G0 load(n)   | G1 mfma(n-1)
-//      interval 2n+1 : G0 mfma(n)   | G1 load(n)
+// The two waves that share a SIMD (wave w and w+4) sit in different groups that order the SAME phase differently, with one
+// s_barrier per phase (interval k = the time between barriers k-1 and k):
+//      G0, interval k : MFMA(k)  (fragments read in interval k-1)   -> read fragments(k+1) -> issue DMA chunk -> counted wait
+//      G1, interval k : read fragments(k) -> issue DMA chunk -> lgkmcnt(0) -> MFMA(k) -> counted wait
+// so on every SIMD one wave's 8 MFMAs run while its partner reads LDS and issues the LDS-DMA refill, and the matrix pipe is
+// handed from G0 to G1 inside the interval without a barrier in between (the previous two-barriers-per-phase form measured
+// 1.87 PF with neither reads nor DMA: each hand-over through a barrier idles the pipe ~70 cycles).
 // K tiles live in two LDS buffers.  Per wave a tile is J = (256 + 64 NP)/64 DMA instructions of 8 rows x 128 B, issued as a
-// stream ordered by first use  [S0, R0..R3, S1, .., S(NP-1)]  cut into NP chunks; chunk q is issued in the load section of phase
-// q - LEAD, i.e. LEAD phases (LEAD x 512 cycles) before the phase that first reads it, and stays in flight across barriers
-// (counted s_waitcnt vmcnt, raw s_barrier; never drained in the steady state).
-//   RAW: every wave waits for ITS share of the data of phase n+1 inside interval 2n+1 (G0: end of mfma(n), G1: end of load(n));
-//        barrier B(2n+1) then orders all shares before G0's load(n+1) (interval 2n+2) and G1's (2n+3).
-//   WAR: a block last read in phase m has been read by G0 in interval 2m (returned by its lgkmcnt(0) in 2m+1) and by G1 in
-//        2m+1 (returned in 2m+2), so its LDS may be refilled from G0's load(m+2) / G1's load(m+1) on.  R is read in phase 0,
-//        S_c in phase c, and the refill of tile t+2 into tile t's buffer honours  issue phase >= m + 2  iff  LEAD <= 2 NP - 2.
+// stream ordered by first use  [S0, R0..R3, S1, .., S(NP-1)]  cut into NP chunks; chunk q is issued in interval q - LEAD and
+// stays in flight across barriers (counted s_waitcnt vmcnt, raw s_barrier; never drained in the steady state).
+//   RAW: the data of phase p is read by G0 in interval p-1 and by G1 in interval p; every wave waits for ITS share of it inside
+//        interval p-2, and barrier p-2 orders all shares before the first read.
+//   WAR: a block last read in phase m has been read (and the read retired by lgkmcnt(0)) by G0 before its MFMA(m) and by G1
+//        before its MFMA(m), both inside interval m, so its LDS may be refilled from interval m+1 on.  R is read in phase 0,
+//        S_c in phase c; the refill of tile t+2 into tile t's buffer honours  issue interval >= m + 1  iff  LEAD <= 2 NP - 1.
 // Accumulation order per output element is the same ascending-k chain of 32x32x16 MFMAs as gemm_nt_kernel: bit-identical results.
 template <int NP>
 struct PPCfg {
@@ -489,10 +597,10 @@ struct PPCfg {
   static constexpr int cnt(int c) { return NP == 3 ? (c == 0 ? 3 : 2) : 2; }   // instructions in chunk c
   static constexpr int cum(int k) { int s = 0; for (int i = 0; i < k; ++i) s += cnt(i); return s; }
   static constexpr int need(int c) { return 5 + c; }              // leading instructions of a tile that phase c reads
-  // vmcnt to wait for before phase c of a tile with `rem` tiles left (incl. itself; >= 3 = steady state), waited right after
-  // chunk (phase - 1 + LEAD) was issued
+  // vmcnt that guarantees the data of phase c of a tile with `rem` tiles left (incl. itself; >= 3 = steady state) has landed,
+  // when waited two intervals ahead, i.e. right after chunk (phase - 2 + LEAD) was issued
   static constexpr int allowed(int c, int rem, int LEAD) {
-    const int x = c - 1 + LEAD;
+    const int x = c - 2 + LEAD;
     const int steady = J * (x / NP) + cum(x % NP + 1) - need(c);
     const int tail = J * rem - need(c);
     return (rem >= 3 || steady < tail) ? steady : tail;
@@ -505,13 +613,18 @@ struct PPCfg {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NP, bool RA, int LEAD>
+// (A persistent variant - min(#tiles, #CUs) workgroups walking the tiles with the next tile's first K tile prefetched under the
+// epilogue - measured 2-5 % SLOWER than one workgroup per tile: it keeps all CUs' store bursts in lockstep and costs 50 VGPRs.)
+//
+// ABL (development ablations, -DV3A_GEMM_ABL builds only; results are garbage): bit 0 = no LDS-DMA in the K loop, bit 1 = no
+// fragment reads, bit 2 = no MFMAs, bit 3 = no s_setprio.
+template <int NP, bool RA, int LEAD, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   using T = PPCfg<NP>;
   constexpr int RB = T::RB, STAGE = T::STAGE, J = T::J;
   constexpr int BM = RA ? 256 : 64 * NP, BN = RA ? 64 * NP : 256;
   constexpr int MT = RA ? 2 : NP, NTL = RA ? NP : 2;
-  static_assert(LEAD >= 1 && LEAD <= 2 * NP - 2, "refill would overtake the readers of the buffer");
+  static_assert(LEAD >= 2 && LEAD <= 2 * NP - 1, "refill would overtake the readers of the buffer");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -522,21 +635,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   const int hi = lane >> 5, l31 = lane & 31;
 
   const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
-  const int tl = xcd_remap(blockIdx.x, tilesM * tilesN);
-  constexpr int GM = RA ? 4 : 8;      // grouped raster: near-square patch of tiles in flight per XCD
-  int tm, tn;
-  {
-    const int gsz = GM * tilesN, gid = tl / gsz, first = gid * GM;
-    const int gm = min(tilesM - first, GM), r = tl - gid * gsz;
-    tm = first + r % gm; tn = r / gm;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-
+  const int ntiles = tilesM * tilesN;
   // R / S side views of the two operands
   const char* Rp = RA ? p.A : p.B;
   const char* Sp = RA ? p.B : p.A;
   const int ldR = RA ? p.lda : p.ldb, ldS = RA ? p.ldb : p.lda;
-  const int r0 = RA ? m0 : n0, s0 = RA ? n0 : m0;
   const int Rn = RA ? p.M : p.N, Sn = RA ? p.N : p.M;
 
   // ---- per-lane DMA sources in stream order; LDS image row-major 128-B rows, chunk' = chunk ^ ((row >> 1) & 7) ----
@@ -545,18 +648,30 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const bool isR = (j >= 1 && j <= 4);
-    int row;  // row inside the R or S region (multiple of 8 per instruction)
-    if (isR) row = ((j - 1) * 8 + wave) * 8;
-    else row = (wave >> 2) * (32 * NP) + (j == 0 ? 0 : j - 4) * 32 + (wave & 3) * 8;
+    const int row = isR ? ((j - 1) * 8 + wave) * 8 : (wave >> 2) * (32 * NP) + (j == 0 ? 0 : j - 4) * 32 + (wave & 3) * 8;
     ldst[j] = (isR ? 0 : T::RROWS * RB) + row * RB;
-    const int rl = row + (lane >> 3);
-    const int c = (lane & 7) ^ ((rl >> 1) & 7);
-    int grow = (isR ? r0 : s0) + rl;
-    const int lim = isR ? Rn : Sn;
-    grow = grow < lim ? grow : lim - 1;
-    gp[j] = (isR ? Rp : Sp) + ((size_t)grow * (isR ? ldR : ldS)) * 2 + c * 16;
   }
-  // chunk cc of the next not-yet-issued tile -> stage `buf`
+  // output tile `id` -> its origin; DMA sources rewound to K = 0
+  auto setup = [&](int id, int& m0, int& n0) {
+    const int tl = xcd_remap(id, ntiles);
+    constexpr int GM = RA ? 4 : 8;    // grouped raster: near-square patch of tiles in flight per XCD
+    const int gsz = GM * tilesN, gid = tl / gsz, first = gid * GM;
+    const int gm = min(tilesM - first, GM), r = tl - gid * gsz;
+    m0 = (first + r % gm) * BM; n0 = (r / gm) * BN;
+    const int r0 = RA ? m0 : n0, s0 = RA ? n0 : m0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const bool isR = (j >= 1 && j <= 4);
+      const int row = isR ? ((j - 1) * 8 + wave) * 8 : (wave >> 2) * (32 * NP) + (j == 0 ? 0 : j - 4) * 32 + (wave & 3) * 8;
+      const int rl = row + (lane >> 3);
+      const int c = (lane & 7) ^ ((rl >> 1) & 7);
+      int grow = (isR ? r0 : s0) + rl;
+      const int lim = isR ? Rn : Sn;
+      grow = grow < lim ? grow : lim - 1;
+      gp[j] = (isR ? Rp : Sp) + ((size_t)grow * (isR ? ldR : ldS)) * 2 + c * 16;
+    }
+  };
+  // chunk cc of the next not-yet-issued K tile -> stage `buf`
   auto issue = [&](auto cc_tag, int buf) {
     constexpr int cc = decltype(cc_tag)::value;
 #pragma unroll
@@ -565,14 +680,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
       gp[j] += RB;
     }
   };
-
-  f32x16 acc[MT][NTL];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NTL; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nk = p.K / 64;
+  // prologue chunks [Q0, Q1) of an output tile (chunk q belongs to K tile q / NP)
+  auto prologue = [&](auto q0_tag, auto q1_tag) {
+    constexpr int Q0 = decltype(q0_tag)::value, Q1 = decltype(q1_tag)::value;
+    auto pro = [&](auto q_tag) {
+      constexpr int q = decltype(q_tag)::value;
+      if constexpr (q >= Q0 && q < Q1) {
+        if (q / NP < nk) issue(std::integral_constant<int, q % NP>{}, (q / NP) & 1);
+      }
+    };
+    pro(std::integral_constant<int, 0>{}); pro(std::integral_constant<int, 1>{}); pro(std::integral_constant<int, 2>{});
+    pro(std::integral_constant<int, 3>{}); pro(std::integral_constant<int, 4>{}); pro(std::integral_constant<int, 5>{});
+    pro(std::integral_constant<int, 6>{});
+  };
 
   const int sw = (l31 >> 1) & 7;
   int koff[4];
@@ -580,27 +701,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * RB + (((2 * ks + hi) ^ sw) << 4);
   const int roff = (wr * 64) * RB, soff = (T::RROWS + ws * 32 * NP) * RB;
 
-  const int nk = p.K / 64;
-  // ---- prologue: chunks 0 .. LEAD-1 ----
-  {
-    auto pro = [&](auto q_tag) {
-      constexpr int q = decltype(q_tag)::value;
-      if (q / NP < nk) issue(std::integral_constant<int, q % NP>{}, (q / NP) & 1);
-    };
-    pro(std::integral_constant<int, 0>{});
-    if constexpr (LEAD > 1) pro(std::integral_constant<int, 1>{});
-    if constexpr (LEAD > 2) pro(std::integral_constant<int, 2>{});
-    if constexpr (LEAD > 3) pro(std::integral_constant<int, 3>{});
-    if constexpr (LEAD > 4) pro(std::integral_constant<int, 4>{});
-    if constexpr (LEAD > 5) pro(std::integral_constant<int, 5>{});
-    if (nk >= 3) wait_vmcnt<T::allowed(0, 3, LEAD)>();
-    else if (nk == 2) wait_vmcnt<T::allowed(0, 2, LEAD)>();
-    else wait_vmcnt<T::allowed(0, 1, LEAD)>();
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 now runs one interval behind group 0
-  }
-
-  bf16x8 rf[2][4], sf[4];
+  f32x16 acc[MT][NTL];
+  bf16x8 rf[2][4] = {}, sf[4] = {};
   // counted wait for the data of phase nc of a tile with nrem tiles left (including itself); exact in the tail, where fewer
   // instructions than the steady-state count are outstanding behind the needed ones
   auto wait_phase = [&](auto nc_tag, int nrem) {
@@ -610,14 +712,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     else if (nrem == 2) wait_vmcnt<a2>();
     else if (nrem == 1) wait_vmcnt<a1>();
   };
-  // one K tile.  BUF = its stage, rem = tiles left including this one (wave-uniform).
-  auto tile = [&](auto buf_tag, const int rem) {
-    constexpr int BUF = decltype(buf_tag)::value;
-    const char* sR = smem + BUF * STAGE + roff;
-    const char* sS = smem + BUF * STAGE + soff;
-    auto phase = [&](auto c_tag) {
-      constexpr int c = decltype(c_tag)::value;
-      // ---------------- load section ----------------
+  // fragments of phase c of the tile in stage BUF
+  auto read_frags = [&](auto buf_tag, auto c_tag) {
+    constexpr int BUF = decltype(buf_tag)::value, c = decltype(c_tag)::value;
+    if constexpr (ABL & 2) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 x0 = sf[ks], x1 = rf[0][ks], x2 = rf[1][ks];
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
+        sf[ks] = x0; rf[0][ks] = x1; rf[1][ks] = x2;
+      }
+    } else {
+      const char* sR = smem + BUF * STAGE + roff;
+      const char* sS = smem + BUF * STAGE + soff;
       if constexpr (c == 0) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -626,18 +733,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) sf[ks] = *(const bf16x8*)(sS + c * 32 * RB + koff[ks]);
-      // chunk (c + LEAD) of the stream belongs to tile t + (c + LEAD) / NP
-      if ((c + LEAD) / NP < rem) issue(std::integral_constant<int, (c + LEAD) % NP>{}, BUF ^ (((c + LEAD) / NP) & 1));
-      // data of the NEXT phase
-      constexpr int nc = c + 1 < NP ? c + 1 : 0;
-      const int nrem = c + 1 < NP ? rem : rem - 1;
-      if (grp == 1) wait_phase(std::integral_constant<int, nc>{}, nrem);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      // ---------------- MFMA section ----------------
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+    }
+  };
+  auto mfma_phase = [&](auto c_tag) {
+    constexpr int c = decltype(c_tag)::value;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
+    if constexpr (!(ABL & 4)) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -645,28 +748,90 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
           if constexpr (RA) acc[b][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf[ks], rf[b][ks], acc[b][c], 0, 0, 0);
           else acc[c][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf[b][ks], sf[ks], acc[c][b], 0, 0, 0);
         }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (grp == 0) wait_phase(std::integral_constant<int, nc>{}, nrem);
-      __builtin_amdgcn_s_barrier();
-    };
-    phase(std::integral_constant<int, 0>{});
-    phase(std::integral_constant<int, 1>{});
-    phase(std::integral_constant<int, 2>{});
-    if constexpr (NP > 3) phase(std::integral_constant<int, 3>{});
-  };
-  {
-    int t = 0;
-    for (; t + 1 < nk; t += 2) {
-      tile(std::integral_constant<int, 0>{}, nk - t);
-      tile(std::integral_constant<int, 1>{}, nk - t - 1);
     }
-    if (t < nk) tile(std::integral_constant<int, 0>{}, 1);
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align the groups: every fragment read has returned, no DMA in flight
+    if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // refill (chunk interval + LEAD), the counted wait for the data of phase interval + 2, then the interval's barrier
+  auto refill_wait_barrier = [&](auto buf_tag, auto c_tag, const int rem) {
+    constexpr int BUF = decltype(buf_tag)::value, c = decltype(c_tag)::value;
+    if (!(ABL & 1) && (c + LEAD) / NP < rem) issue(std::integral_constant<int, (c + LEAD) % NP>{}, BUF ^ (((c + LEAD) / NP) & 1));
+    constexpr int nc = (c + 2) % NP;
+    wait_phase(std::integral_constant<int, nc>{}, c + 2 < NP ? rem : rem - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
 
-  if constexpr (RA) gemm_epilogue<MT, NTL>(p, acc, smem, wave, lane, m0 + wr * 64, n0 + ws * 32 * NP);
-  else gemm_epilogue<MT, NTL>(p, acc, smem, wave, lane, m0 + ws * 32 * NP, n0 + wr * 64);
+  int m0, n0;
+  setup(blockIdx.x, m0, n0);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  {
+    // ---- prologue: chunks 0 .. LEAD-1, then the data of phases 0 and 1 ----
+    prologue(I0{}, std::integral_constant<int, LEAD>{});
+    wait_phase(I1{}, nk);   // interval "-1": chunk LEAD-1 was the last one issued
+    __builtin_amdgcn_s_barrier();
+    if (grp == 0) {
+      // ---------------- group 0: MFMA first, then next phase's fragments + refill ----------------
+      auto tile = [&](auto buf_tag, const int rem) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        auto phase = [&](auto c_tag) {
+          constexpr int c = decltype(c_tag)::value;
+          mfma_phase(c_tag);
+          if constexpr (c + 1 < NP) read_frags(buf_tag, std::integral_constant<int, c + 1>{});
+          else if (rem > 1) read_frags(std::integral_constant<int, BUF ^ 1>{}, I0{});
+          refill_wait_barrier(buf_tag, c_tag, rem);
+        };
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        if constexpr (NP > 3) phase(std::integral_constant<int, 3>{});
+      };
+      read_frags(I0{}, I0{});
+      int t = 0;
+      for (; t + 1 < nk; t += 2) {
+        tile(I0{}, nk - t);
+        tile(I1{}, nk - t - 1);
+      }
+      if (t < nk) tile(I0{}, 1);
+    } else {
+      // ---------------- group 1: fragments + refill first, then MFMA ----------------
+      auto tile = [&](auto buf_tag, const int rem) {
+        auto phase = [&](auto c_tag) {
+          read_frags(buf_tag, c_tag);
+          constexpr int BUF = decltype(buf_tag)::value, c = decltype(c_tag)::value;
+          if (!(ABL & 1) && (c + LEAD) / NP < rem) issue(std::integral_constant<int, (c + LEAD) % NP>{}, BUF ^ (((c + LEAD) / NP) & 1));
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_phase(c_tag);
+          constexpr int nc = (c + 2) % NP;
+          wait_phase(std::integral_constant<int, nc>{}, c + 2 < NP ? rem : rem - 1);
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+        };
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        if constexpr (NP > 3) phase(std::integral_constant<int, 3>{});
+      };
+      int t = 0;
+      for (; t + 1 < nk; t += 2) {
+        tile(I0{}, nk - t);
+        tile(I1{}, nk - t - 1);
+      }
+      if (t < nk) tile(I0{}, 1);
+    }
+    // every fragment read has returned (lgkmcnt(0) precedes the last MFMAs) and no DMA is in flight (the tail waits reach 0):
+    // both stages are free
+    const int em = m0 + (RA ? wr * 64 : ws * 32 * NP), en = n0 + (RA ? ws * 32 * NP : wr * 64);
+    if constexpr (!(ABL & 32)) gemm_add_bias<MT, NTL>(p, acc, lane, em, en);
+    gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8), (ABL >> 4) & 3>(p, acc, smem, wave, lane, em, en);
+  }
 }
 
 typedef void (*gemm_fn)(const GemmP);
@@ -675,7 +840,6 @@ struct TileEntry {
   int BM, BN, nthr, lds;
   gemm_fn fn, conv_fn;
 };
-
 template <int BM, int BN, int WM, int WN, int BK, int NS, int STG>
 constexpr gemm_fn conv_kernel_or_null() {
   if constexpr (TileCfg<BM, BN, WM, WN, BK, NS>::CONV_OK) return (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, true, STG>;
@@ -694,6 +858,10 @@ constexpr gemm_fn conv_kernel_or_null() {
   { "pp_np" #NP "_ra" #RA "_l" #LEAD, (RA) ? 256 : 64 * NP, (RA) ? 64 * NP : 256, 512, PPCfg<NP>::LDS_BYTES, \
     (gemm_fn)gemm_pp_kernel<NP, RA, LEAD>, nullptr }
 
+#define PP_ABL(NP, RA, LEAD, ABL)                                                                  \
+  { "pp_np" #NP "_l" #LEAD "_abl" #ABL, (RA) ? 256 : 64 * NP, (RA) ? 64 * NP : 256, 512, PPCfg<NP>::LDS_BYTES, \
+    (gemm_fn)gemm_pp_kernel<NP, RA, LEAD, ABL>, nullptr }
+
 const TileEntry kTiles[] = {
     TILE_ENTRY(256, 192, 4, 2, 64, 2),  // 0: N % 192 == 0 shapes (d=1536): 8192x1536 -> exactly 256 tiles
     TILE_ENTRY(192, 256, 2, 4, 64, 2),  // 1: transposed role of 0 (V^T = Wv . X^T)
@@ -708,31 +876,39 @@ const TileEntry kTiles[] = {
     TILE_ENTRY_OCC(192, 128, 2, 2, 32, 2, 4),  // 9
     TILE_ENTRY_OCC(192, 256, 2, 4, 32, 2, 2),  // 10: transposed role of 6
     // ping-pong main loop (gemm_pp_kernel), one 8-wave workgroup per CU
-    PP_ENTRY(3, true, 4),    // 11: 256x192
-    PP_ENTRY(4, true, 6),    // 12: 256x256
-    PP_ENTRY(3, false, 4),   // 13: 192x256
-    PP_ENTRY(4, true, 4),    // 14: 256x256, shorter DMA lead (tuning)
-    PP_ENTRY(3, true, 3),    // 15: 256x192, shorter DMA lead (tuning)
+    PP_ENTRY(3, true, 5),    // 11: 256x192
+    PP_ENTRY(4, true, 7),    // 12: 256x256
+    PP_ENTRY(3, false, 5),   // 13: 192x256
+    PP_ENTRY(4, true, 5),    // 14: 256x256, shorter DMA lead (tuning)
+    PP_ENTRY(3, true, 4),    // 15: 256x192, shorter DMA lead (tuning)
+#ifdef V3A_GEMM_ABL
+    PP_ABL(4, true, 7, 1), PP_ABL(4, true, 7, 2), PP_ABL(4, true, 7, 3), PP_ABL(4, true, 7, 4), PP_ABL(4, true, 7, 5), PP_ABL(4, true, 7, 6),
+    PP_ABL(4, true, 7, 7), PP_ABL(4, true, 7, 8),
+    PP_ABL(3, true, 5, 1), PP_ABL(3, true, 5, 3), PP_ABL(3, true, 5, 4), PP_ABL(3, true, 5, 16), PP_ABL(3, true, 5, 32),
+#endif
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 int g_attr_lds[kNumTiles][2] = {};
 
-constexpr int kAutoTiles = 7;  // tiles the heuristic may choose from (the rest are explicit / tuning variants)
+// tiles the heuristic may choose from (the rest are explicit / tuning variants); the ping-pong tiles have no conv form
+constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 13};
 int pick_tile(int M, int N, bool conv = false) {
-  // minimise (#rounds over 256 CUs) x (tile area incl. padding waste); prefer bigger tiles on ties.
+  // minimise (#rounds over 256 CUs) x (tile area incl. padding waste) / (measured main-loop efficiency of the tile family)
   double best = 1e30;
   int bi = 5;
-  for (int i = 0; i < kAutoTiles; ++i) {
+  for (int i : kAutoList) {
     const TileEntry& e = kTiles[i];
     if (conv && !e.conv_fn) continue;
     long tm = (M + e.BM - 1) / e.BM, tn = (N + e.BN - 1) / e.BN;
     long tiles = tm * tn;
-    int per_cu = (e.lds <= 80 * 1024) ? 2 : 1;
+    const bool pp = i >= 11;
+    int per_cu = (!pp && e.lds <= 80 * 1024) ? 2 : 1;
     long slots = 256L * per_cu;
     long rounds = (tiles + slots - 1) / slots;
     // co-resident small tiles run ~concurrently: cost per round ~ per_cu tiles' area, small efficiency bonus for large tiles
     double eff = (e.BM * e.BN >= 256 * 192) ? 1.0 : (e.BM * e.BN >= 128 * 256 ? 0.9 : 0.8);
     if (i == 6) eff = 1.06;  // 256x192 two-per-CU: measured +5..14 % over tile 0 once every CU holds two workgroups
+    if (pp) eff = (i == 12) ? 1.20 : 1.14;  // ping-pong main loop: measured +8..14 % (256x192 / 192x256), more at 256x256
     double cost = (double)rounds * per_cu * e.BM * e.BN / eff;
     if (cost < best - 1e-9) { best = cost; bi = i; }
   }
