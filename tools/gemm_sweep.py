@@ -17,14 +17,14 @@ lib = L.load()
 names = [lib.v3a_gemm_tile_name(t).decode() for t in range(lib.v3a_gemm_num_tiles())]
 
 
-def run(M, N, K, tile, res=False, iters=20, rounds=3):
+def run(M, N, K, tile, res=False, iters=20, rounds=3, act=0):
     a = torch.randn(M, K, device="cuda", generator=g).to(bf16)
     w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(bf16)
     b = torch.randn(N, device="cuda", generator=g)
     out = torch.empty(M, N, device="cuda", dtype=bf16)
     r = torch.randn(M, N, device="cuda", generator=g).to(bf16) if res else None
     args = L.GemmArgs(a.data_ptr(), w.data_ptr(), out.data_ptr(), b.data_ptr(), r.data_ptr() if res else None, None, M, N, K, K, K, N,
-                      N if res else 0, 0, 0, 0, 0, tile, None, 0, 0, 0, 0, 0)
+                      N if res else 0, 0, 0, act, 0, tile, None, 0, 0, 0, 0, 0)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     f = lib.v3a_gemm_bf16_nt
     for _ in range(3):
@@ -43,6 +43,7 @@ def run(M, N, K, tile, res=False, iters=20, rounds=3):
 
 
 if __name__ == "__main__":
+    ACT = int(__import__('os').environ.get('ACT', '0'))
     tiles = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else list(range(len(names)))
     shapes = ((8192, 1536, 1536, True), (8192, 3072, 1536, False), (8192, 8960, 1536, False), (8192, 1536, 8960, True),
               (1536, 8192, 1536, False), (4096, 1536, 1536, True), (8192, 5120, 5120, False), (8192, 13824, 5120, False),
@@ -55,7 +56,7 @@ if __name__ == "__main__":
         row, ref = {}, None
         for tile in tiles:
             g.manual_seed(1234)
-            us, out, _ = run(M, N, K, tile, res=res)
+            us, out, _ = run(M, N, K, tile, res=res, act=ACT)
             if ref is None:
                 ref = out.clone()
             row[names[tile]] = dict(tf=round(2 * M * N * K / us / 1e6), us=round(us, 1), bit_equal=bool(torch.equal(out, ref)))

@@ -83,10 +83,10 @@ struct TileCfg {
 // The epilogue is latency-, not bandwidth-bound when written naively (a dependent global load per quad / per row chunk:
 // measured 7 us of a 38 us FFN1 tile), so every global load is issued ahead of its use: the bias in one batch before phase 1, and
 // residual / gate loads in batches of PFB row chunks, with EARLY the first batch of a group BEFORE phase 1 so that its latency
-// hides under the convert-and-park work (the two-workgroups-per-CU tiles have no registers for that).
-template <int MT, int NTL, int PFB, bool EARLY, int DBG = 0, bool BIAS_P1 = false>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane,
-                                              int mw0, int nw) {
+// hides under the convert-and-park work (not with a 128-register accumulator, where it would spill).
+template <int ACT, int MT, int NTL, int PFB, bool EARLY, int DBG>
+__device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane,
+                                                  int mw0, int nw) {
   constexpr int WTN = NTL * 32, PITCH = WTN * 2 + 8;
   if constexpr (DBG & 2) {   // development ablation: no epilogue at all (accumulators kept live)
 #pragma unroll
@@ -100,9 +100,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
   constexpr int CH = WTN / 8;
   constexpr int ITERS = 32 * CH / 64;
   static_assert((32 * CH) % 64 == 0, "epilogue chunking");
-  constexpr int PB = PFB > 0 ? PFB : 1;   // PFB = 0: loads issued inside each row chunk (register-capped two-per-CU tiles)
-  static_assert(ITERS % PB == 0, "prefetch batch");
-  const int act = p.act, flags = p.flags;
+  constexpr int PB = PFB;
+  static_assert(PFB > 0 && ITERS % PB == 0, "prefetch batch");
+  const int flags = p.flags;
   const bool res_f32 = (flags & V3A_GEMM_RES_F32) != 0;
 
   // prefetched operands of one row chunk (8 consecutive columns of one output row)
@@ -138,45 +138,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 #pragma unroll
       for (int s = 0; s < PB; ++s) fetch(mw, s, s);
     }
-    float brow = 0.f;
-    const bool bias_row = (flags & V3A_GEMM_BIAS_ROW) != 0;
-    if (BIAS_P1 && p.bias && bias_row) {
-      const int m = mw + l31;
-      brow = p.bias[m < p.M ? m : p.M - 1];
-    }
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e];
-        if (BIAS_P1 && p.bias) {   // register-capped tiles: bias loaded per quad (no room for gemm_add_bias's batch)
-          const int n = nw + j * 32 + g * 8 + hi * 4;
-          if (bias_row) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += brow;
-          } else if (n + 3 < p.N) {
-            const f32x4 bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bv[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) v[e] += p.bias[n + e];
-          }
-        }
         u32x2 pk;
-        pk[0] = pack_bf16x2(v[0], v[1]);
-        pk[1] = pack_bf16x2(v[2], v[3]);
+        pk[0] = pack_bf16x2(acc[i][j][g * 4], acc[i][j][g * 4 + 1]);
+        pk[1] = pack_bf16x2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
         *(u32x2*)(reg + l31 * PITCH + (j * 32 + g * 8 + hi * 4) * 2) = pk;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-#pragma unroll(PFB > 0 ? ITERS : 2)
+#pragma unroll
     for (int it0 = 0; it0 < ITERS; it0 += PB) {
-      if (PFB > 0 && (!EARLY || it0 > 0)) {
+      if (!EARLY || it0 > 0) {
 #pragma unroll
         for (int s = 0; s < PB; ++s) fetch(mw, it0 + s, s);
       }
@@ -187,18 +163,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
         const u32x2 lo = *(const u32x2*)(reg + ml * PITCH + ch * 16);
         const u32x2 hi2 = *(const u32x2*)(reg + ml * PITCH + ch * 16 + 8);
         if (m >= p.M || n >= p.N) continue;
-        if constexpr (PFB == 0) fetch(mw, it0, 0);
         u32x4 raw;
         raw[0] = lo[0]; raw[1] = lo[1]; raw[2] = hi2[0]; raw[3] = hi2[1];
         float v[8];
         unpack_bf16x8(raw, v);
-        if (act != V3A_ACT_NONE) {
+        if constexpr (ACT != V3A_ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             float x = v[e];
-            if (act == V3A_ACT_GELU_TANH) x = gelu_tanh(x);
-            else if (act == V3A_ACT_GELU_ERF) x = gelu_erf(x);
-            else if (act == V3A_ACT_SILU) x = silu(x);
+            if constexpr (ACT == V3A_ACT_GELU_TANH) x = gelu_tanh(x);
+            else if constexpr (ACT == V3A_ACT_GELU_ERF) x = gelu_erf(x);
+            else if constexpr (ACT == V3A_ACT_SILU) x = silu(x);
             else x = fmaxf(x, 0.f);
             v[e] = round_bf16(x);
           }
@@ -255,9 +230,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
   }
 }
 
+// The activation is resolved ONCE per launch: with the switch inside the element loops the epilogue grew to 16 k instructions
+// of scalar branches (five activations x 8 elements x every row chunk) and thrashed the instruction cache - any activation,
+// even ReLU, cost FFN1 +70 us.
+template <int MT, int NTL, int PFB, bool EARLY, int DBG = 0>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane,
+                                              int mw0, int nw) {
+  switch (p.act) {
+    case V3A_ACT_GELU_TANH: gemm_epilogue_act<V3A_ACT_GELU_TANH, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
+    case V3A_ACT_GELU_ERF: gemm_epilogue_act<V3A_ACT_GELU_ERF, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
+    case V3A_ACT_SILU: gemm_epilogue_act<V3A_ACT_SILU, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
+    case V3A_ACT_RELU: gemm_epilogue_act<V3A_ACT_RELU, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
+    default: gemm_epilogue_act<V3A_ACT_NONE, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
+  }
+}
+
 // acc += bias (fp32), ahead of the epilogue: all bias loads of the wave tile are issued together (one exposed latency instead of
 // one per accumulator quad) and only once, since the column bias is the same for every 32-row group.
-template <int MT, int NTL, bool LIGHT = false>   // LIGHT: one 32-column block at a time (register-capped two-per-CU tiles)
+template <int MT, int NTL>
 __device__ __forceinline__ void gemm_add_bias(const GemmP& p, f32x16 (&acc)[MT][NTL], int lane, int mw0, int nw) {
   const int hi = lane >> 5, l31 = lane & 31;
   if (!p.bias) return;
@@ -270,26 +260,6 @@ __device__ __forceinline__ void gemm_add_bias(const GemmP& p, f32x16 (&acc)[MT][
       for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] += b;
-    }
-  } else if constexpr (LIGHT) {
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) {
-      f32x4 bq[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = nw + j * 32 + g * 8 + hi * 4;
-        if (n + 3 < p.N) bq[g] = *(const f32x4*)(p.bias + n);
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bq[g][e] = n + e < p.N ? p.bias[n + e] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[i][j][g * 4 + e] += bq[g][e];
     }
   } else {
     f32x4 bq[NTL][4];
@@ -320,10 +290,8 @@ __device__ __forceinline__ void gemm_add_bias(const GemmP& p, f32x16 (&acc)[MT][
 //          are issued, and the slab t+1 registers written to LDS, BETWEEN the MFMA groups of slab t.  An LDS-DMA instruction
 //          occupies its wave for ~100+ cycles at issue and every wave of the workgroup issues them at the same point, so
 //          DMA staging leaves the matrix pipe idle for ~40 % of each slab (measured: 1468 TF without refill vs 830 with).
-// OCC = workgroups the kernel is compiled to co-reside per CU (register cap = 512 / (OCC * waves per SIMD)): with OCC = 2
-// one workgroup's epilogue / DMA-issue bubbles are filled by the other's MFMAs.
-template <int BM, int BN, int WM, int WN, int BK, int NS, bool CONV, int STG, int OCC = 1>
-__global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_kernel(const GemmP p) {
+template <int BM, int BN, int WM, int WN, int BK, int NS, bool CONV, int STG>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel(const GemmP p) {
   using T = TileCfg<BM, BN, WM, WN, BK, NS>;
   constexpr int NW = T::NW, MT = T::MT, NTL = T::NTL, NL = T::NL, STAGE = T::STAGE;
   constexpr int WTM = T::WTM, WTN = T::WTN, PITCH = T::PITCH;
@@ -343,7 +311,7 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_
   // Grouped raster: consecutive tiles walk down a band of GM row-tiles before moving to the next column, so the ~64 tiles in
   // flight on one XCD (and the XCD's whole contiguous chunk) cover a near-square patch: 8 A row-panels + 8 W panels per 64
   // tiles instead of 1-2 A panels + every W panel (FFN1: 535 MB -> ~260 MB of L2 fills per launch).
-  constexpr int GM = (OCC * 32 * BN / BM >= 36) ? 8 : 4;  // ~sqrt(tiles in flight per XCD x BN/BM): squarest in-flight patch
+  constexpr int GM = (32 * BN / BM >= 36) ? 8 : 4;  // ~sqrt(tiles in flight per XCD x BN/BM): squarest in-flight patch
   int tm, tn;
   {
     const int gsz = GM * tilesN, gid = t / gsz, first = gid * GM;
@@ -563,8 +531,8 @@ __global__ __launch_bounds__(WM* WN * 64, (OCC * WM * WN + 3) / 4) void gemm_nt_
     __builtin_amdgcn_s_barrier();  // all fragment reads retired before the ring is reused by the epilogue
   }
 
-  if constexpr (OCC == 1) gemm_add_bias<MT, NTL>(p, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
-  gemm_epilogue<MT, NTL, (OCC > 1 ? 0 : (NTL < 3 ? 2 : NTL)), (OCC == 1 && MT * NTL < 8), 0, (OCC > 1)>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+  gemm_add_bias<MT, NTL>(p, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
+  gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8)>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
 // =====================================================================================================================
@@ -850,10 +818,6 @@ constexpr gemm_fn conv_kernel_or_null() {
     TileCfg<BM, BN, WM, WN, BK, NS>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, false, STG>, \
     conv_kernel_or_null<BM, BN, WM, WN, BK, NS, STG>() }
 #define TILE_ENTRY(BM, BN, WM, WN, BK, NS) TILE_ENTRY_S(BM, BN, WM, WN, BK, NS, 0)
-#define TILE_ENTRY_OCC(BM, BN, WM, WN, BK, NS, OCC)                                                 \
-  { #BM "x" #BN "_w" #WM "x" #WN "_k" #BK "s" #NS "_occ" #OCC, BM, BN, TileCfg<BM, BN, WM, WN, BK, NS>::NTHR, \
-    TileCfg<BM, BN, WM, WN, BK, NS>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, false, 0, OCC>, nullptr }
-
 #define PP_ENTRY(NP, RA, LEAD)                                                                      \
   { "pp_np" #NP "_ra" #RA "_l" #LEAD, (RA) ? 256 : 64 * NP, (RA) ? 64 * NP : 256, 512, PPCfg<NP>::LDS_BYTES, \
     (gemm_fn)gemm_pp_kernel<NP, RA, LEAD>, nullptr }
@@ -863,27 +827,18 @@ constexpr gemm_fn conv_kernel_or_null() {
     (gemm_fn)gemm_pp_kernel<NP, RA, LEAD, ABL>, nullptr }
 
 const TileEntry kTiles[] = {
-    TILE_ENTRY(256, 192, 4, 2, 64, 2),  // 0: N % 192 == 0 shapes (d=1536): 8192x1536 -> exactly 256 tiles
-    TILE_ENTRY(192, 256, 2, 4, 64, 2),  // 1: transposed role of 0 (V^T = Wv . X^T)
+    TILE_ENTRY(256, 192, 4, 2, 64, 2),  // 0: lockstep main loop (also the implicit-GEMM convolution): N % 192 == 0 shapes
+    TILE_ENTRY(192, 256, 2, 4, 64, 2),  // 1: transposed role of 0
     TILE_ENTRY(256, 256, 2, 4, 64, 2),  // 2
     TILE_ENTRY(128, 256, 2, 4, 64, 2),  // 3
     TILE_ENTRY(256, 128, 4, 2, 64, 2),  // 4
     TILE_ENTRY(128, 128, 2, 2, 64, 2),  // 5: small / ragged problems, 2 workgroups per CU
-    // two (or four) co-resident workgroups per CU: one's epilogue / DMA-issue bubbles are filled by the others' MFMAs
-    TILE_ENTRY_OCC(256, 192, 4, 2, 32, 2, 2),  // 6: 56 KiB ring; +14 % on shapes with >= 2 tiles per CU (QK, FFN1)
-    TILE_ENTRY_OCC(128, 192, 2, 2, 32, 2, 4),  // 7: 40 KiB, 4 waves, up to 4 per CU
-    TILE_ENTRY_OCC(128, 192, 2, 2, 64, 2, 2),  // 8: 80 KiB, 4 waves, 2 per CU
-    TILE_ENTRY_OCC(192, 128, 2, 2, 32, 2, 4),  // 9
-    TILE_ENTRY_OCC(192, 256, 2, 4, 32, 2, 2),  // 10: transposed role of 6
     // ping-pong main loop (gemm_pp_kernel), one 8-wave workgroup per CU
-    PP_ENTRY(3, true, 5),    // 11: 256x192
-    PP_ENTRY(4, true, 7),    // 12: 256x256
-    PP_ENTRY(3, false, 5),   // 13: 192x256
-    PP_ENTRY(4, true, 5),    // 14: 256x256, shorter DMA lead (tuning)
-    PP_ENTRY(3, true, 4),    // 15: 256x192, shorter DMA lead (tuning)
+    PP_ENTRY(3, true, 5),    // 6: 256x192 (d = 1536 = 8 x 192: 8192x1536 -> exactly 256 tiles)
+    PP_ENTRY(4, true, 7),    // 7: 256x256
+    PP_ENTRY(3, false, 5),   // 8: 192x256 (V^T = Wv . X^T)
 #ifdef V3A_GEMM_ABL
     PP_ABL(4, true, 7, 1), PP_ABL(4, true, 7, 2), PP_ABL(4, true, 7, 3), PP_ABL(4, true, 7, 4), PP_ABL(4, true, 7, 5), PP_ABL(4, true, 7, 6),
-    PP_ABL(4, true, 7, 7), PP_ABL(4, true, 7, 8),
     PP_ABL(3, true, 5, 1), PP_ABL(3, true, 5, 3), PP_ABL(3, true, 5, 4), PP_ABL(3, true, 5, 16), PP_ABL(3, true, 5, 32),
 #endif
 };
@@ -891,7 +846,7 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 int g_attr_lds[kNumTiles][2] = {};
 
 // tiles the heuristic may choose from (the rest are explicit / tuning variants); the ping-pong tiles have no conv form
-constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 13};
+constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
 int pick_tile(int M, int N, bool conv = false) {
   // minimise (#rounds over 256 CUs) x (tile area incl. padding waste) / (measured main-loop efficiency of the tile family)
   double best = 1e30;
@@ -901,14 +856,13 @@ int pick_tile(int M, int N, bool conv = false) {
     if (conv && !e.conv_fn) continue;
     long tm = (M + e.BM - 1) / e.BM, tn = (N + e.BN - 1) / e.BN;
     long tiles = tm * tn;
-    const bool pp = i >= 11;
+    const bool pp = i >= 6;
     int per_cu = (!pp && e.lds <= 80 * 1024) ? 2 : 1;
     long slots = 256L * per_cu;
     long rounds = (tiles + slots - 1) / slots;
     // co-resident small tiles run ~concurrently: cost per round ~ per_cu tiles' area, small efficiency bonus for large tiles
     double eff = (e.BM * e.BN >= 256 * 192) ? 1.0 : (e.BM * e.BN >= 128 * 256 ? 0.9 : 0.8);
-    if (i == 6) eff = 1.06;  // 256x192 two-per-CU: measured +5..14 % over tile 0 once every CU holds two workgroups
-    if (pp) eff = (i == 12) ? 1.20 : 1.14;  // ping-pong main loop: measured +8..14 % (256x192 / 192x256), more at 256x256
+    if (pp) eff = (i == 7) ? 1.20 : 1.14;  // ping-pong main loop: measured +8..14 % (256x192 / 192x256), more at 256x256
     double cost = (double)rounds * per_cu * e.BM * e.BN / eff;
     if (cost < best - 1e-9) { best = cost; bi = i; }
   }
