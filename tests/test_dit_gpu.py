@@ -293,3 +293,32 @@ def test_merged_padding_keys_equal_full_cross_attention(tiny):
     one_pad = full.clone()
     one_pad[:, -1] = 0                                                           # a single zero row is not worth a merge
     assert torch.equal(model(lat, t, one_pad)[0], plain(lat, t, one_pad)[0])
+
+
+def test_full_depth_production_size_forward_matches_oracle(hip_lib, parity):
+    """The one full-size parity point: Wan-1.3B geometry (30 blocks, 12 x 128 heads, FFN 8960), 13 views @512 (4096 tokens), B=1,
+    random bf16-representable weights, against oracle.dit_forward with the bf16 rounding points emulated (~35 s on the GPU box's
+    host cores).  This is the only test in which the production GEMM tiles (ping-pong 256x192 / 192x256) and the three-per-CU hd128
+    flash kernel run inside the model AND are compared with a reference.  Text context 77 tokens + padding to 512 (merged)."""
+    import dataclasses
+    from vist3a_amd.wan.dit import WAN_1_3B, WanDiT
+    cfg = dataclasses.replace(WAN_1_3B, text_dim=512)   # UMT5 width 4096 only scales the (cached) context MLP
+    ocfg = O.WanDiTConfig(num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim, ffn_dim=cfg.ffn_dim,
+                          num_layers=cfg.num_layers, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=11).items()}
+    model = WanDiT(cfg, sd, device="cuda")
+    g = torch.Generator().manual_seed(12)
+    lat = torch.randn(1, 16, 4, 64, 64, generator=g).to(torch.bfloat16)
+    text = (torch.randn(1, 512, cfg.text_dim, generator=g) * 0.5).to(torch.bfloat16).float()
+    text[:, 77:] = 0
+    t = torch.tensor([700])
+    out = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
+    r = _rel(out, ref)
+    mx = (out - ref).abs().max().item()
+    parity("dit_full_depth_30_blocks_N4096", rel_vs_emu_oracle=r, max_abs=mx, ref_rms=ref.pow(2).mean().sqrt().item())
+    print(f"full-depth 30-block N=4096 forward: rel {r:.3e} max abs {mx:.3e}")
+    assert torch.isfinite(out).all()
+    assert r < 3e-2, r

@@ -165,3 +165,79 @@ def _gather_cpu(group, r):
     o = torch.empty(group.world, 1)
     group.all_gather(o, torch.tensor([10.0 * r])).wait()
     return o.view(-1)
+
+
+def test_merge_lora_matches_reference_eval_merge_golden():
+    """recon/weights.merge_lora against tests/golden/lora_tiny.safetensors: the `lora` dict written by the reference's
+    lora_state_dict(bias="lora_only") and the weights its add_lora + load_state_dict + .eval() produce (make_golden_lora.py)."""
+    from pathlib import Path
+    from safetensors import safe_open
+    from vist3a_amd.recon.weights import merge_lora
+    f = safe_open(str(Path(__file__).parent / "golden" / "lora_tiny.safetensors"), "pt")
+    meta = f.metadata()
+    grp = lambda p: {k[len(p):]: f.get_tensor(k) for k in f.keys() if k.startswith(p)}
+    base, lora, merged, io = grp("base/"), grp("lora/"), grp("merged/"), grp("io/")
+    assert any(k.endswith(".bias") for k in lora), "the checkpoint layout carries trained biases"
+    sd = {k: v.clone() for k, v in base.items()}
+    n = merge_lora(sd, lora, float(meta["alpha"]), int(meta["r"]))
+    assert n == 6 and set(sd) == set(merged)
+    for k in merged:
+        assert torch.allclose(sd[k], merged[k], atol=1e-6), k
+    changed = [k for k in merged if k.endswith(".bias") and not torch.equal(base[k], merged[k])]
+    assert len(changed) == 4   # qkv x2 and both convs: the biases a weight-only merge would silently drop
+    # the merged weights reproduce the reference module's outputs
+    y = torch.nn.functional.linear(torch.nn.functional.linear(io["x"], sd["blocks.0.qkv.weight"], sd["blocks.0.qkv.bias"])[..., :12], sd["blocks.1.proj.weight"])
+    z = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(io["img"], sd["head.0.weight"], sd["head.0.bias"], padding=1)), sd["head.2.weight"], sd["head.2.bias"])
+    assert torch.allclose(y, io["y"], atol=1e-5) and torch.allclose(z, io["z"], atol=1e-5)
+    # unknown keys must not be dropped silently
+    import pytest
+    with pytest.raises(KeyError):
+        merge_lora({k: v.clone() for k, v in base.items()}, {**lora, "blocks.7.qkv.bias": torch.zeros(36)}, 16.0, 4)
+
+
+def test_parse_lora_mode_matches_reference_parser_golden():
+    import json
+    from pathlib import Path
+    from safetensors import safe_open
+    from vist3a_amd.utils.argument import parse_lora_mode
+    meta = safe_open(str(Path(__file__).parent / "golden" / "lora_tiny.safetensors"), "pt").metadata()
+    for spec, (r, alpha) in json.loads(meta["specs"]).items():
+        if ",f1" in spec:
+            continue
+        assert parse_lora_mode(spec) == (r, alpha), spec
+    import pytest
+    for bad in ("x3", "r", "bfoo"):
+        with pytest.raises(ValueError):
+            parse_lora_mode(bad)
+
+
+def test_load_peft_lora_folder_layout(tmp_path):
+    """`lora_ema/` as /root/reference/train_vdm.py:32-97 writes it through peft (adapter_config.json + adapter_model.safetensors with
+    `base_model.model.<module>.lora_{A,B}.weight`) and /root/reference/inference_t23d.py:74-77 reads it.  peft itself is not
+    installed here (parity unpinned): the folder is written by hand in the published adapter format."""
+    import json
+    from safetensors.torch import save_file
+    from vist3a_amd.wan.weights import load_peft_lora
+    g = torch.Generator().manual_seed(5)
+    d, r, alpha = 16, 4, 8
+    sd = {f"blocks.{i}.attn1.{n}.weight": torch.randn(d, d, generator=g).to(torch.bfloat16) for i in range(2) for n in ("to_q", "to_k", "to_v", "to_out.0")}
+    ref = {k: v.float().clone() for k, v in sd.items()}
+    ad = {}
+    for k in list(sd)[:5]:
+        mod = k[: -len(".weight")]
+        A, B = torch.randn(r, d, generator=g) * 0.1, torch.randn(d, r, generator=g) * 0.1
+        ad[f"base_model.model.{mod}.lora_A.weight"], ad[f"base_model.model.{mod}.lora_B.weight"] = A, B
+        ref[k] = ref[k] + (alpha / r) * (B @ A)
+    save_file(ad, str(tmp_path / "adapter_model.safetensors"))
+    (tmp_path / "adapter_config.json").write_text(json.dumps({"peft_type": "LORA", "r": r, "lora_alpha": alpha,
+                                                               "target_modules": ["to_q", "to_k", "to_v", "to_out.0"]}))
+    assert load_peft_lora(str(tmp_path), sd) == 5
+    for k in sd:
+        assert torch.allclose(sd[k].float(), ref[k], atol=1e-6), k          # merged in fp32, not re-rounded to the checkpoint dtype
+    bad = dict(ad)
+    bad["base_model.model.blocks.9.attn1.to_q.lora_A.weight"] = torch.zeros(r, d)
+    bad["base_model.model.blocks.9.attn1.to_q.lora_B.weight"] = torch.zeros(d, r)
+    save_file(bad, str(tmp_path / "adapter_model.safetensors"))
+    import pytest
+    with pytest.raises(KeyError):
+        load_peft_lora(str(tmp_path), sd)

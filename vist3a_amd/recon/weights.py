@@ -116,18 +116,36 @@ def round_aggregator_to_bf16(sd: SD) -> SD:
 
 
 def merge_lora(sd: SD, lora_sd: SD, alpha: float, r: int) -> int:
-    """loralib-style adapters saved by /root/reference/model_stitching_training.py:59-72 (`…lora_A` [r,in], `…lora_B` [out,r];
-    Conv2d: lora_A [r*k, in*k], lora_B [out*k, r*k] reshaped to the conv weight).  W += (B @ A).view_as(W) * alpha / r —
-    what Linear.train(False) / ConvLoRA.train(False) do when the reference calls .eval() (lora_util/layers.py:149-165,338-355)."""
-    n = 0
-    for key, A in lora_sd.items():
-        if not key.endswith("lora_A"):
+    """Apply the `lora` entry of a stitched checkpoint (/root/reference/model_stitching_training.py:59-72 saves
+    `lora_state_dict(model, bias="lora_only")`, utils/lora_util/utils.py:35-54) to the base weights `sd`, the way the reference's
+    evaluation loader does with add_lora + load_state_dict(strict=False) + .eval() (nvs_eval.py:37-50):
+      * `<layer>.lora_A` [r,in] / `.lora_B` [out,r] (Conv2d: [r*k, in*k] / [out*k, r*k], view-ed to the kernel shape):
+        W += (B @ A).view_as(W) * alpha / r  - what Linear.train(False) / ConvLoRA.train(False) do (layers.py:149-165,338-355);
+      * every other key is a trained parameter of a LoRA-wrapped layer (its `bias`, also reachable as `<layer>.conv.bias` for a
+        wrapped Conv2d) and REPLACES the base value.
+    A key that names nothing in `sd` raises: a silently dropped bias gives wrong reconstructions with no other symptom.
+    Returns the number of merged matrices.  Pinned by tests/golden/lora_tiny.safetensors (made by the reference's own code)."""
+    n, unknown = 0, []
+    for key, v in lora_sd.items():
+        if key.endswith("lora_B"):
+            if key[: -len("lora_B")] + "lora_A" not in lora_sd:
+                unknown.append(key)
             continue
-        base = key[: -len("lora_A")]
-        B = lora_sd.get(base + "lora_B")
-        w = base + "weight"
-        if B is None or w not in sd:
+        if key.endswith("lora_A"):
+            base = key[: -len("lora_A")]
+            B = lora_sd.get(base + "lora_B")
+            w = base + "weight"
+            if B is None or w not in sd:
+                unknown.append(key)
+                continue
+            sd[w] = (sd[w].float() + (B.float() @ v.float()).view(sd[w].shape) * (alpha / r)).to(sd[w].dtype)
+            n += 1
             continue
-        sd[w] = (sd[w].float() + (B.float() @ A.float()).view(sd[w].shape) * (alpha / r)).to(sd[w].dtype)
-        n += 1
+        tgt = key if key in sd else key.replace(".conv.", ".")
+        if tgt not in sd or sd[tgt].shape != v.shape:
+            unknown.append(key)
+            continue
+        sd[tgt] = v.to(sd[tgt].dtype)
+    if unknown:
+        raise KeyError(f"LoRA checkpoint keys without a target in the base weights: {unknown[:8]}{' ...' if len(unknown) > 8 else ''}")
     return n

@@ -44,18 +44,31 @@ def inference_vist3a_argument() -> argparse.ArgumentParser:
 
 
 def parse_lora_mode(spec: str):
-    """'r64,a32,d0.0,f0' -> (r, alpha): the two numbers the merged-at-load LoRA needs (utils/lora_util/utils.py:68-117 grammar)."""
-    r, alpha = 8, 16
+    """'r64,a32,d0.0,f0' -> (r, alpha): the two numbers the merged-at-load LoRA needs.  Grammar and defaults (r=8, alpha=32) of
+    /root/reference/utils/lora_util/utils.py:57-117 (`LoraConfig`, `parse_lora_mode`); pinned by tests/golden/lora_tiny.safetensors."""
+    import re
+    r, alpha = 8, 32
+    pat = re.compile(r"(?P<key>[radbf t])(?:(?P<num>[\d.]+)|(?P<str>[^,]+))")
     for chunk in spec.split(","):
         c = chunk.strip().lower()
-        if c in ("enc", "fix_head", "fixhead") or not c:
+        if c in ("enc", "fix_head", "fixhead"):
             continue
-        if c[0] == "r" and c[1:].isdigit():
-            r = int(c[1:])
-        elif c[0] == "a" and c[1:].replace(".", "").isdigit():
-            alpha = int(float(c[1:]))
-        elif c[0] in "dbtf":
-            continue
-        else:
+        m = pat.fullmatch(c)
+        if not m:
             raise ValueError(f"Bad LoRA chunk: {c!r}")
+        k = m["key"]
+        if k in "radf" and m["num"] is None:
+            raise ValueError(f"Bad LoRA chunk: {c!r}")
+        if k == "r":
+            r = int(m["num"])
+        elif k == "a":
+            alpha = int(m["num"])
+        elif k == "d":
+            float(m["num"])
+        elif k == "b":
+            if m["str"] not in {"none", "all", "lora_only"}:
+                raise ValueError("b chunk must be none|all|lora_only")
+        elif k == "f":
+            if bool(int(m["num"])):
+                raise NotImplementedError("fan_in_fan_out LoRA layers (f1) are not supported by the merged-at-load path")
     return r, alpha

@@ -82,7 +82,9 @@ def merge_lora_into_state_dict(sd: Dict[str, torch.Tensor], lora_sd: Dict[str, t
         wname = base + ".weight"
         if wname not in sd or kb not in lora_sd:
             raise KeyError(f"LoRA target {wname} not found in base state dict")
-        sd[wname] = (sd[wname].float() + (alpha / r) * (lora_sd[kb].float() @ A.float())).to(sd[wname].dtype)
+        # kept in fp32: WanDiT._load rounds to bf16 exactly once (rounding to a bf16/fp16 checkpoint dtype first would quantise the
+        # rank-r delta at the ulp of W twice)
+        sd[wname] = sd[wname].float() + (alpha / r) * (lora_sd[kb].float() @ A.float())
         n += 1
     return n
 
