@@ -391,3 +391,30 @@ def test_norm_kernels_production_shapes(hip_lib, parity):
         r = relerr(y, torch.view_as_real(nc * fc).reshape(M, d).to(bf16))
         parity("rmsnorm_rope", B=B, N=N, rel_vs_fp32=r)
         assert r < 2e-4, r
+
+
+@pytest.mark.parametrize("spread", [0.03, 0.25], ids=["7_points_per_voxel", "1_point_per_voxel"])
+def test_voxel_fusion_production_size_matches_scatter_reference(hip_lib, parity, spread):
+    """R13 at 13 x 448^2 points x 84 columns: voxel ids bit-exact vs torch.unique on the rounded coordinates; fused features and
+    positions vs a torch scatter-softmax (scatter_max / exp / scatter_add, anysplat.py:298-335) to fp32 round-off."""
+    from vist3a_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    M, C = 13 * 448 * 448, 83
+    pts = (torch.randn(M, 3, device=dev, generator=g) * spread).contiguous()
+    feat = torch.randn(M, C + 1, device=dev, generator=g).contiguous()
+    v = ops.voxelize_fuse(pts, feat, C, C, 0.002)
+    U, inv = v["keys"].shape[0], v["inverse"].long()
+    keys = (pts / 0.002).round().int()
+    uq, uinv, ucnt = torch.unique(keys, dim=0, return_inverse=True, return_counts=True)
+    assert torch.equal(v["keys"], uq) and torch.equal(inv, uinv) and torch.equal(v["counts"].long(), ucnt)
+    conf = feat[:, C]
+    mx = torch.full((U,), -float("inf"), device=dev).scatter_reduce(0, inv, conf, "amax")
+    ex = torch.exp(conf - mx[inv])
+    w = ex / (torch.zeros(U, device=dev).index_add_(0, inv, ex) + 1e-6)[inv]
+    rf = torch.zeros(U, C, device=dev).index_add_(0, inv, feat[:, :C] * w[:, None])
+    rp = torch.zeros(U, 3, device=dev).index_add_(0, inv, pts * w[:, None])
+    ef, ep = relerr(v["voxel_feat"][:, :C], rf), relerr(v["voxel_pts"], rp)
+    parity("voxel_fusion_production", M=M, U=U, rel_feat=ef, rel_pts=ep)
+    assert ef < 1e-6 and ep < 1e-6, (ef, ep)
+    again = ops.voxelize_fuse(pts, feat, C, C, 0.002)
+    assert torch.equal(again["voxel_feat"], v["voxel_feat"]) and torch.equal(again["voxel_pts"], v["voxel_pts"])   # fixed summation order

@@ -6,8 +6,7 @@
 // ((kx+2^20)<<42 | (ky+2^20)<<21 | (kz+2^20)) sorted with a stable LSD radix sort (rocPRIM device primitive, the one
 // library call in this file), run-length boundaries by an exclusive scan.  Because the sort is stable, every voxel's
 // points appear in ascending original index: the float sums have ONE defined order (the reference's CUDA atomics
-// have none).  The fusion pass gives one wave to a voxel at a time: lanes span the feature channels, so every point
-// row (<= 88 floats) is one coalesced read.
+// have none).  The fusion pass gives a 16-lane group to a voxel (see fuse_kernel).
 #include "common.h"
 #include "../../include/vist3a_hip.h"
 #include <cstring>
@@ -65,30 +64,64 @@ struct FuseP {
   const unsigned int* idx; const unsigned int* start; const int* U;
   float* vpts; float* vfeat; int ldo; int* counts;
 };
+// One 16-LANE GROUP per voxel (four voxels per wave, grid-stride): real scenes put 1-3 points in a voxel, so a whole wave per
+// voxel idles 3/4 of its lanes and serialises four dependent round trips (start -> idx -> confidence -> row) per voxel.
+// Per voxel: (1) the group gathers the confidences of its points 16 at a time and reduces the maximum with 4 shuffles;
+// (2) ONE pass over the points in sorted (= ascending original index) order: e_j = exp(c_j - max) is computed 16 points at a
+// time (lane i holds point i), then for each point its row index and e_j are broadcast inside the group and the row is read as
+// NK independent 64-byte pieces (lane sl takes channels sl + 16 k): NK loads in flight per point, accumulated with one FMA each.
+// The normaliser is applied once at the end: sum_j f_j e_j / (sum_j e_j + 1e-6)  ==  sum_j f_j softmax_j  up to one rounding.
+// Every sum runs in a fixed order (points ascending, then a fixed shuffle tree for the denominator): results do not depend on
+// scheduling.  Replaces the three-serial-passes-per-wave kernel that ran at 1 % of HBM bandwidth (11.4 ms per scene).
+template <int NK>
 __global__ __launch_bounds__(256) void fuse_kernel(const FuseP p) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, sl = lane & 15, gbase = lane & 48;
   const int U = *p.U;
-  const int nw = gridDim.x * 4;
-  for (int u = blockIdx.x * 4 + (threadIdx.x >> 6); u < U; u += nw) {
+  const int ngroups = gridDim.x * 16;
+  const size_t ldf = (size_t)p.ldf;
+  for (int u = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4); u < U; u += ngroups) {
     const unsigned s = p.start[u], e = p.start[u + 1];
-    if (lane == 0) p.counts[u] = (int)(e - s);
-    // softmax over the confidences of the voxel's points (scatter_max, exp, scatter_add, +1e-6)
+    if (sl == 0) p.counts[u] = (int)(e - s);
     float mx = -INFINITY;
-    for (unsigned j = s; j < e; ++j) mx = fmaxf(mx, p.feat[(size_t)p.idx[j] * p.ldf + p.conf_col]);
-    float den = 0.f;
-    for (unsigned j = s; j < e; ++j) den += expf(p.feat[(size_t)p.idx[j] * p.ldf + p.conf_col] - mx);
-    den += 1e-6f;
-    float a0 = 0.f, a1 = 0.f, ap = 0.f;
-    for (unsigned j = s; j < e; ++j) {
-      const size_t r = p.idx[j];
-      const float w = expf(p.feat[r * p.ldf + p.conf_col] - mx) / den;
-      if (lane < p.nfeat) a0 += p.feat[r * p.ldf + lane] * w;
-      if (lane + 64 < p.nfeat) a1 += p.feat[r * p.ldf + lane + 64] * w;
-      if (lane < 3) ap += p.pts[r * 3 + lane] * w;
+    for (unsigned j0 = s; j0 < e; j0 += 16) {
+      const unsigned j = j0 + sl;
+      if (j < e) mx = fmaxf(mx, p.feat[(size_t)p.idx[j] * ldf + p.conf_col]);
     }
-    if (lane < p.nfeat) p.vfeat[(size_t)u * p.ldo + lane] = a0;
-    if (lane + 64 < p.nfeat) p.vfeat[(size_t)u * p.ldo + lane + 64] = a1;
-    if (lane < 3) p.vpts[(size_t)u * 3 + lane] = ap;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+    float acc[NK], ap = 0.f, dpart = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) acc[k] = 0.f;
+    for (unsigned j0 = s; j0 < e; j0 += 16) {
+      const unsigned j = j0 + sl;
+      unsigned myr = 0;
+      float mye = 0.f;
+      if (j < e) {
+        myr = p.idx[j];
+        mye = expf(p.feat[(size_t)myr * ldf + p.conf_col] - mx);
+      }
+      dpart += mye;
+      const int cnt = (int)min(16u, e - j0);
+      for (int i = 0; i < cnt; ++i) {
+        const size_t r = (size_t)__shfl(myr, gbase + i, 64);
+        const float w = __shfl(mye, gbase + i, 64);
+        const float* row = p.feat + r * ldf;
+        float v[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) v[k] = (sl + 16 * k < p.nfeat) ? row[sl + 16 * k] : 0.f;
+        const float pv = sl < 3 ? p.pts[r * 3 + sl] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) acc[k] = fmaf(v[k], w, acc[k]);
+        ap = fmaf(pv, w, ap);
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dpart += __shfl_xor(dpart, o, 16);
+    const float inv = 1.0f / (dpart + 1e-6f);
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+      if (sl + 16 * k < p.nfeat) p.vfeat[(size_t)u * p.ldo + sl + 16 * k] = acc[k] * inv;
+    if (sl < 3) p.vpts[(size_t)u * 3 + sl] = ap * inv;
   }
 }
 
@@ -151,7 +184,9 @@ extern "C" int v3a_voxelize_fuse(const float* pts, const float* feat, int ldf, i
     return V3A_ERR_LAUNCH;
   hipLaunchKernelGGL(segments_kernel, dim3(nb), dim3(256), 0, stream,
                      SegP{key_out, idx_out, head, vid, M, keys_out, inverse_out, start, num_voxels});
-  hipLaunchKernelGGL(fuse_kernel, dim3(2048), dim3(256), 0, stream,
-                     FuseP{pts, feat, ldf, nfeat, conf_col, idx_out, start, num_voxels, voxel_pts, voxel_feat, ldo, counts_out});
+  const FuseP fp{pts, feat, ldf, nfeat, conf_col, idx_out, start, num_voxels, voxel_pts, voxel_feat, ldo, counts_out};
+  if (nfeat <= 32) hipLaunchKernelGGL(fuse_kernel<2>, dim3(2048), dim3(256), 0, stream, fp);
+  else if (nfeat <= 96) hipLaunchKernelGGL(fuse_kernel<6>, dim3(2048), dim3(256), 0, stream, fp);
+  else hipLaunchKernelGGL(fuse_kernel<8>, dim3(2048), dim3(256), 0, stream, fp);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
