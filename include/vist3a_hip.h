@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 6) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 7) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -201,6 +201,13 @@ long v3a_voxelize_workspace_bytes(long M);
 int v3a_voxelize_fuse(const float* pts, const float* feat, int ldf, int nfeat, int conf_col, long M, float voxel_size,
                       void* workspace, long workspace_bytes, int* keys_out, int* inverse_out, int* counts_out,
                       float* voxel_pts, float* voxel_feat, int ldo, int* num_voxels, int* status, void* stream);
+/* confidence-quantile mask + row compaction (the voxelize = False branch): threshold = torch.quantile(conf[M], q) ("linear"),
+ * rows with conf > threshold are copied in row-major order to out_pts[.][3] / out_feat[.][ldo]; *count_out (device int) = rows kept,
+ * *threshold_out (device float) = the quantile.  M <= 2^24.  /root/reference/models/anysplat_stitched.py:381-387, 441-446 */
+long v3a_conf_compact_workspace_bytes(long M);
+int v3a_conf_quantile_compact(const float* conf, float q, const float* pts, const float* feat, int ldf, int nfeat, long M,
+                              void* workspace, long workspace_bytes, float* threshold_out, float* out_pts, float* out_feat, int ldo,
+                              int* count_out, void* stream);
 /* UnifiedGaussianAdapter + opacity map: feats[U][ldf] = {density logit, 3 scale, 4 quat xyzw, 3*(deg+1)^2 SH}
  * common/gaussian_adapter.py:114-147, common/gaussians.py:33-44, anysplat.py:225-238 (opacity_exponent = 2^x) */
 int v3a_gaussian_adapter(const float* pts, const float* feats, int ldf, long U, int sh_degree, float opacity_exponent,

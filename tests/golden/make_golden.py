@@ -224,7 +224,33 @@ def voxel_collide():
                             "keys": keys, "inverse": inv.to(torch.int32), "counts": cnt.to(torch.int32)})
 
 
-GENERATORS = {f.__name__: f for f in [vae_decode_tiny, vae_encode_tiny, stitch_tiny, recon_tiny, voxel_collide]}
+def recon_tiny_conf():
+    """Same reduced-width model as recon_tiny with encoder.cfg.voxelize = False and render_conf = True: the confidence-quantile
+    mask branch of AnySplatStitched.forward (anysplat_stitched.py:381-387, 441-446).  Stores the depth confidences, the quantile,
+    the mask and the compacted Gaussian means / opacities (boolean-mask order = row-major)."""
+    from oracle import recon as R
+    cfg = R.ReconCfg(**RECON_TINY)
+    sd = R.make_recon_weights(cfg, seed=41)
+    model = build_reference_stitched(cfg, sd)
+    model.encoder.cfg.voxelize, model.encoder.cfg.render_conf, model.encoder.cfg.conf_threshold = False, True, 0.1
+    g = torch.Generator().manual_seed(42)
+    S, H, W = 2, 28, 28
+    lat = torch.randn(1, cfg.C, S, H // 14, W // 14, generator=g)
+    img = torch.rand(1, 3, S, H, W, generator=g) * 2 - 1
+    import contextlib, io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        ref, _anchor, _conf, dconf = model(lat, img, True)   # train=True also returns depth_conf (anysplat_stitched.py:501-514)
+    q = torch.quantile(dconf.flatten(0, 1), 0.1)
+    mask = dconf > q
+    assert torch.equal(mask, ref.depth_dict["conf_valid_mask"])
+    gs = ref.gaussians
+    assert gs.means.shape[1] == int(mask.sum())
+    print(f"recon_tiny_conf: kept {int(mask.sum())} of {mask.numel()} points; quantile {q.item():.6f}")
+    _save("recon_tiny_conf", {"latent": lat, "image": img, "depth_conf": dconf, "quantile": q.reshape(1), "mask": mask.to(torch.uint8),
+                              "means": gs.means, "opacities": gs.opacities, "scales": gs.scales})
+
+
+GENERATORS = {f.__name__: f for f in [vae_decode_tiny, vae_encode_tiny, stitch_tiny, recon_tiny, recon_tiny_conf, voxel_collide]}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)

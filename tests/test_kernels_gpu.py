@@ -404,7 +404,9 @@ def test_voxel_fusion_production_size_matches_scatter_reference(hip_lib, parity,
     feat = torch.randn(M, C + 1, device=dev, generator=g).contiguous()
     v = ops.voxelize_fuse(pts, feat, C, C, 0.002)
     U, inv = v["keys"].shape[0], v["inverse"].long()
-    keys = (pts / 0.002).round().int()
+    # tensor / tensor = IEEE division, what the reference's CPU path computes (torch's GPU tensor / python-scalar kernel multiplies by
+    # the reciprocal instead and differs in the last bit for a handful of points)
+    keys = (pts / torch.full_like(pts, 0.002)).round().int()
     uq, uinv, ucnt = torch.unique(keys, dim=0, return_inverse=True, return_counts=True)
     assert torch.equal(v["keys"], uq) and torch.equal(inv, uinv) and torch.equal(v["counts"].long(), ucnt)
     conf = feat[:, C]

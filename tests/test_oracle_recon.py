@@ -74,3 +74,22 @@ def test_small_pieces():
     tok = torch.arange(2 * 3.0).view(1, 2, 1, 3)
     o = R.slice_expand_and_flatten(tok, 1, 4)
     assert torch.equal(o[0], tok[0, 0]) and all(torch.equal(o[i], tok[0, 1]) for i in (1, 2, 3))
+
+
+def test_conf_mask_branch_golden():
+    """voxelize=False + render_conf=True (anysplat_stitched.py:381-387, 441-446) against the reference's own forward."""
+    g = load_file(str(G / "recon_tiny_conf.safetensors"))
+    cfg = R.ReconCfg(**RECON_TINY, voxelize=False, render_conf=True, conf_threshold=0.1)
+    sd = R.make_recon_weights(cfg, seed=41)
+    with torch.no_grad():
+        o = R.recon_forward(sd, cfg, g["latent"], g["image"])
+    assert torch.allclose(o["depth_conf"], g["depth_conf"], rtol=2e-4, atol=1e-5)
+    # the oracle's own confidences differ from the reference's in the last bits: compare the mask where the margin is not round-off
+    far = (g["depth_conf"] - g["quantile"]).abs() > 1e-3
+    assert torch.equal(o["conf_valid_mask"][far], g["mask"].bool()[far])
+    if torch.equal(o["conf_valid_mask"], g["mask"].bool()):
+        assert torch.allclose(o["gaussians"]["means"], g["means"], atol=2e-5)
+        assert torch.allclose(o["gaussians"]["opacities"], g["opacities"], atol=2e-5)
+    # the mask arithmetic itself, on the reference's confidences: index-exact
+    q = torch.quantile(g["depth_conf"].flatten(0, 1), 0.1)
+    assert torch.equal(q.reshape(1), g["quantile"]) and torch.equal(g["depth_conf"] > q, g["mask"].bool())

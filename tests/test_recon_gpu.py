@@ -141,3 +141,51 @@ def test_gaussian_tail_on_identical_inputs(tiny):
         assert torch.allclose(a, b, rtol=2e-4, atol=1e-6), (k, (a - b).abs().max())
     # (no index-for-index comparison with the golden file here: the oracle's own fp32 points differ in the last bit between
     #  host CPUs, which can move a point across a voxel boundary; tests/test_oracle_recon.py pins the oracle to the golden.)
+
+
+def test_conf_quantile_mask_compaction_is_index_exact(hip_lib):
+    """R13' (voxelize=False, render_conf=True): HIP quantile + row compaction vs the reference golden (its depth confidences, its
+    torch.quantile value and its boolean-mask order) and, at production size, vs torch.quantile + boolean indexing: bit-exact."""
+    from safetensors.torch import load_file
+    from pathlib import Path
+    from vist3a_amd import ops
+    g = load_file(str(Path(__file__).parent / "golden" / "recon_tiny_conf.safetensors"))
+    conf = g["depth_conf"].reshape(-1).cuda().contiguous()
+    M = conf.numel()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    pts = torch.randn(M, 3, device="cuda", generator=gen)
+    feat = torch.randn(M, 84, device="cuda", generator=gen)
+    c = ops.conf_quantile_compact(conf, 0.1, pts, feat, 83)
+    mask = g["mask"].bool().reshape(-1).cuda()
+    assert torch.equal(c["threshold"].cpu().reshape(1), g["quantile"])
+    assert torch.equal(c["pts"], pts[mask]) and torch.equal(c["feat"], feat[mask][:, :83])
+    for (M, q) in ((13 * 448 * 448, 0.1), (1000, 0.5), (4097, 0.0), (777, 1.0), (2, 0.3)):
+        conf = (torch.randn(M, device="cuda", generator=gen) * 3).exp()
+        conf[::7] = conf[min(3, M - 1)].clone()   # ties around any threshold
+        pts = torch.randn(M, 3, device="cuda", generator=gen)
+        feat = torch.randn(M, 84, device="cuda", generator=gen)
+        c = ops.conf_quantile_compact(conf, q, pts, feat, 83)
+        tq = torch.quantile(conf, q)
+        assert torch.equal(c["threshold"], tq), (M, q, c["threshold"].item(), tq.item())
+        m = conf > tq
+        assert torch.equal(c["pts"], pts[m]) and torch.equal(c["feat"], feat[m][:, :83])
+
+
+def test_engine_conf_mask_branch_matches_reference_golden(hip_lib):
+    from safetensors.torch import load_file
+    from pathlib import Path
+    from vist3a_amd.recon.engine import ReconCfg, ReconEngine
+    g = load_file(str(Path(__file__).parent / "golden" / "recon_tiny_conf.safetensors"))
+    kw = dict(C=64, heads=1, n_dino=22, depth=24, cam_heads=2, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+    sd = R.make_recon_weights(R.ReconCfg(**kw), seed=41)
+    eng = ReconEngine(ReconCfg(**kw, voxelize=False, render_conf=True, conf_threshold=0.1), sd, "cuda")
+    out = eng.forward(g["latent"], g["image"])
+    K, Kref = out["gaussians"]["means"].shape[0], g["means"].shape[1]
+    dc = out["depth_conf"].float().cpu().reshape(g["depth_conf"].shape)
+    rel = ((dc - g["depth_conf"]).norm() / g["depth_conf"].norm()).item()
+    print(f"conf-mask branch: kept {K} vs reference {Kref}; depth_conf rel {rel:.2e}")
+    assert rel < 2e-2
+    assert abs(K - Kref) <= 1     # the kept count is fixed by the quantile (ties aside), whatever the bf16 noise in the values
+    mask = (dc > out["conf_valid"].cpu())
+    agree = (mask == g["mask"].bool()).float().mean().item()
+    assert agree > 0.97, agree

@@ -147,6 +147,60 @@ Layout layout(long M) {
   return l;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Confidence-quantile mask + stream compaction (SURVEY.md §8a R13', the voxelize = False branch):
+//   /root/reference/models/anysplat_stitched.py:381-387  conf_valid = torch.quantile(depth_conf.flatten(0,1), conf_threshold);
+//                                                          mask = depth_conf > conf_valid
+//   /root/reference/models/anysplat_stitched.py:441-446  feats = anchor_feats.permute(0,2,3,1)[mask];  pts = pts_all[mask]
+// torch.quantile (aten/native/Sorting.cpp quantile_compute, "linear"): sort ascending; rank = q * (n - 1) in the INPUT dtype
+// (fp32); lo = floor(rank), hi = ceil(rank), w = rank - lo; result = lerp(sorted[lo], sorted[hi], w) with ATen's lerp
+// (w < 0.5 ? a + w (b - a) : b - (b - a)(1 - w)).  Restated with a rocPRIM radix sort of the keys; boolean-mask indexing keeps
+// row-major order, i.e. an exclusive scan of the flags gives every kept row its output position (index-exact).
+struct QuantP { const float* sorted; long n; float q; float* out; };
+__global__ void quantile_pick_kernel(const QuantP p) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float rank = p.q * (float)(p.n - 1);
+  const float lo = floorf(rank), hi = ceilf(rank);
+  const float w = rank - lo;
+  const float a = p.sorted[(long)lo], b = p.sorted[(long)hi];
+  *p.out = w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w);
+}
+struct FlagP { const float* conf; const float* thr; long M; unsigned int* flag; };
+__global__ __launch_bounds__(256) void conf_flags_kernel(const FlagP p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < p.M) p.flag[i] = p.conf[i] > *p.thr ? 1u : 0u;
+}
+struct CompactP {
+  const float* pts; const float* feat; int ldf, nfeat; const unsigned int* flag; const unsigned int* pos; long M;
+  float* opts; float* ofeat; int ldo; int* count;
+};
+// one 16-lane group per input row: kept rows are copied as 64-byte pieces to their scanned position
+__global__ __launch_bounds__(256) void compact_rows_kernel(const CompactP p) {
+  const int sl = threadIdx.x & 15;
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  if (i >= p.M) return;
+  if (i == p.M - 1 && sl == 0) *p.count = (int)(p.pos[i] + p.flag[i]);
+  if (!p.flag[i]) return;
+  const size_t o = p.pos[i];
+  for (int c = sl; c < p.nfeat; c += 16) p.ofeat[o * p.ldo + c] = p.feat[(size_t)i * p.ldf + c];
+  if (sl < 3) p.opts[o * 3 + sl] = p.pts[(size_t)i * 3 + sl];
+}
+
+struct CLayout { size_t sorted, flag, pos, thr, tmp, tmp_bytes, total; };
+CLayout clayout(long M) {
+  CLayout l{};
+  size_t off = 0;
+  auto take = [&](size_t b) { size_t o = off; off += align256(b); return o; };
+  l.sorted = take(M * 4); l.flag = take(M * 4); l.pos = take(M * 4); l.thr = take(4);
+  size_t t1 = 0, t2 = 0;
+  (void)rocprim::radix_sort_keys(nullptr, t1, (float*)nullptr, (float*)nullptr, (size_t)M, 0, 32);
+  (void)rocprim::exclusive_scan(nullptr, t2, (unsigned int*)nullptr, (unsigned int*)nullptr, 0u, (size_t)M, rocprim::plus<unsigned int>());
+  l.tmp_bytes = t1 > t2 ? t1 : t2;
+  l.tmp = take(l.tmp_bytes);
+  l.total = off;
+  return l;
+}
 }  // namespace
 
 extern "C" long v3a_voxelize_workspace_bytes(long M) {
@@ -188,5 +242,32 @@ extern "C" int v3a_voxelize_fuse(const float* pts, const float* feat, int ldf, i
   if (nfeat <= 32) hipLaunchKernelGGL(fuse_kernel<2>, dim3(2048), dim3(256), 0, stream, fp);
   else if (nfeat <= 96) hipLaunchKernelGGL(fuse_kernel<6>, dim3(2048), dim3(256), 0, stream, fp);
   else hipLaunchKernelGGL(fuse_kernel<8>, dim3(2048), dim3(256), 0, stream, fp);
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}
+
+extern "C" long v3a_conf_compact_workspace_bytes(long M) { return M > 0 ? (long)clayout(M).total : 0; }
+
+extern "C" int v3a_conf_quantile_compact(const float* conf, float q, const float* pts, const float* feat, int ldf, int nfeat, long M,
+                                         void* workspace, long workspace_bytes, float* threshold_out, float* out_pts, float* out_feat,
+                                         int ldo, int* count_out, void* stream_) {
+  if (!conf || !pts || !feat || !workspace || !threshold_out || !out_pts || !out_feat || !count_out) return V3A_ERR_ARG;
+  if (M <= 0 || M > (1L << 24) || nfeat <= 0 || nfeat > ldf || ldo < nfeat || !(q >= 0.f && q <= 1.f)) return V3A_ERR_SHAPE;  // fp32 rank is exact up to 2^24
+  const CLayout l = clayout(M);
+  if ((size_t)workspace_bytes < l.total) return V3A_ERR_SHAPE;
+  hipStream_t stream = (hipStream_t)stream_;
+  char* ws = (char*)workspace;
+  auto* sorted = (float*)(ws + l.sorted);
+  auto* flag = (unsigned int*)(ws + l.flag);
+  auto* pos = (unsigned int*)(ws + l.pos);
+  size_t tb = l.tmp_bytes;
+  if (rocprim::radix_sort_keys(ws + l.tmp, tb, conf, sorted, (size_t)M, 0, 32, stream) != hipSuccess) return V3A_ERR_LAUNCH;
+  hipLaunchKernelGGL(quantile_pick_kernel, dim3(1), dim3(64), 0, stream, QuantP{sorted, M, q, threshold_out});
+  const unsigned nb = (unsigned)((M + 255) / 256);
+  hipLaunchKernelGGL(conf_flags_kernel, dim3(nb), dim3(256), 0, stream, FlagP{conf, threshold_out, M, flag});
+  tb = l.tmp_bytes;
+  if (rocprim::exclusive_scan(ws + l.tmp, tb, flag, pos, 0u, (size_t)M, rocprim::plus<unsigned int>(), stream) != hipSuccess)
+    return V3A_ERR_LAUNCH;
+  hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)((M * 16 + 255) / 256)), dim3(256), 0, stream,
+                     CompactP{pts, feat, ldf, nfeat, flag, pos, M, out_pts, out_feat, ldo, count_out});
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }

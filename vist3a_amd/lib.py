@@ -150,6 +150,9 @@ SYMBOLS = {
     "v3a_voxelize_workspace_bytes": (C.c_long, [C.c_long]),
     "v3a_voxelize_fuse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float, C.c_void_p, C.c_long]
                           + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v3a_conf_compact_workspace_bytes": (C.c_long, [C.c_long]),
+    "v3a_conf_quantile_compact": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_long,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "v3a_gaussian_adapter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_float] + [C.c_void_p] * 8),
     "v3a_linear_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
     "v3a_attention_small_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),

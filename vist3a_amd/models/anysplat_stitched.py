@@ -56,8 +56,8 @@ class AnySplatStitched(torch.nn.Module):
         aggregator.patch_embed = patch_embed
         self.encoder = torch.nn.Module()
         self.encoder.aggregator = aggregator
-        self.encoder.cfg = SimpleNamespace(voxelize=cfg.voxelize, voxel_size=cfg.voxel_size, pred_head_type="depth", render_conf=False,
-                                           opacity_conf=False, conf_threshold=0.1)
+        self.encoder.cfg = SimpleNamespace(voxelize=cfg.voxelize, voxel_size=cfg.voxel_size, pred_head_type="depth",
+                                           render_conf=cfg.render_conf, opacity_conf=False, conf_threshold=cfg.conf_threshold)
         self.encoder.raw_gs_dim = 1 + 7 + 3 * (cfg.sh_degree + 1) ** 2
         self._decoder = None
         self.grad_checkpointing = False
@@ -78,13 +78,16 @@ class AnySplatStitched(torch.nn.Module):
     def engine(self) -> ReconEngine:
         pe = self.encoder.aggregator.patch_embed
         a = "encoder.aggregator.patch_embed."
-        dirty = self._engine is None or self._cfg.voxelize != self.encoder.cfg.voxelize
+        ec = self.encoder.cfg
+        dirty = (self._engine is None or self._cfg.voxelize != ec.voxelize or self._cfg.render_conf != ec.render_conf
+                 or self._cfg.conf_threshold != ec.conf_threshold)
         for name in ("cls_token", "register_tokens"):
             if not torch.equal(getattr(pe, name).detach().cpu().float(), self._sd[a + name].detach().cpu().float()):
                 self._sd[a + name] = getattr(pe, name).detach().clone()
                 dirty = True
         if dirty:
-            self._cfg.voxelize = bool(self.encoder.cfg.voxelize)
+            self._cfg.voxelize, self._cfg.render_conf = bool(ec.voxelize), bool(ec.render_conf)
+            self._cfg.conf_threshold = float(ec.conf_threshold)
             self._engine = ReconEngine(self._cfg, self._sd, self._device)
         return self._engine
 

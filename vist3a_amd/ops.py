@@ -445,6 +445,25 @@ def voxelize_fuse(pts: torch.Tensor, feat: torch.Tensor, nfeat: int, conf_col: i
     return dict(voxel_pts=vp[:U], voxel_feat=vf[:U], keys=keys[:U], inverse=inv, counts=cnt[:U])
 
 
+def conf_quantile_compact(conf: torch.Tensor, q: float, pts: torch.Tensor, feat: torch.Tensor, nfeat: int):
+    """rows of (pts [M,3], feat[:, :nfeat]) whose confidence exceeds torch.quantile(conf, q), in row-major order ->
+    dict(pts [K,3], feat [K,nfeat], threshold (0-dim f32)).  anysplat_stitched.py:381-387, 441-446."""
+    _chk2d(pts, "pts", (f32,))
+    _chk2d(feat, "feat", (f32,))
+    if conf.dtype != f32 or not conf.is_contiguous() or conf.numel() != pts.shape[0]:
+        raise ValueError("conf must be contiguous f32 with one value per row")
+    M, dev = pts.shape[0], pts.device
+    lib = L.load()
+    ws = torch.empty(int(lib.v3a_conf_compact_workspace_bytes(M)), device=dev, dtype=torch.uint8)
+    op, of = torch.empty(M, 3, device=dev, dtype=f32), torch.empty(M, nfeat, device=dev, dtype=f32)
+    thr = torch.empty((), device=dev, dtype=f32)
+    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    L.check(lib.v3a_conf_quantile_compact(_ptr(conf), float(q), _ptr(pts.contiguous()), _ptr(feat), feat.stride(0), nfeat, M, _ptr(ws), ws.numel(),
+                                          _ptr(thr), _ptr(op), _ptr(of), nfeat, _ptr(cnt), _stream()), "v3a_conf_quantile_compact")
+    K = int(cnt.item())  # one host sync: the Gaussian count sizes every downstream tensor
+    return dict(pts=op[:K], feat=of[:K], threshold=thr)
+
+
 def gaussian_adapter(pts: torch.Tensor, feats: torch.Tensor, sh_mask: torch.Tensor, sh_degree: int = 4, opacity_exponent: float = 1.0):
     _chk2d(feats, "feats", (f32,))
     U, dev, dsh = feats.shape[0], feats.device, (sh_degree + 1) ** 2

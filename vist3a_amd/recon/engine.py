@@ -33,11 +33,12 @@ SD = Dict[str, torch.Tensor]
 class ReconCfg:
     def __init__(self, C=1024, heads=16, n_dino=22, depth=24, cam_heads=16, cam_trunk=4, features=256,
                  oc=(256, 512, 1024, 1024), patch=14, voxel_size=0.002, voxelize=True, sh_degree=4,
-                 taps=(4, 11, 17, 23), opacity_exponent=1.0):
+                 taps=(4, 11, 17, 23), opacity_exponent=1.0, render_conf=False, conf_threshold=0.1):
         self.C, self.heads, self.n_dino, self.depth = C, heads, n_dino, depth
         self.cam_heads, self.cam_trunk, self.features, self.oc = cam_heads, cam_trunk, features, list(oc)
         self.patch, self.voxel_size, self.voxelize, self.sh_degree = patch, voxel_size, voxelize, sh_degree
         self.taps, self.opacity_exponent = tuple(taps), opacity_exponent
+        self.render_conf, self.conf_threshold = render_conf, conf_threshold   # voxelize=False branch only (anysplat_stitched.py:381-387)
 
 
 def uv_pos_embed(C: int, ph: int, pw: int, W: int, H: int, ratio: float = 0.1) -> torch.Tensor:
@@ -356,6 +357,10 @@ class ReconEngine:
             v = ops.voxelize_fuse(pts.view(M, 3), raw_gs, gsd, gsd, cfg.voxel_size)
             vp, vf = v["voxel_pts"], v["voxel_feat"]
             out.update(voxel_keys=v["keys"], voxel_inverse=v["inverse"], voxel_counts=v["counts"])
+        elif cfg.render_conf:
+            c = ops.conf_quantile_compact(dconf.reshape(M), cfg.conf_threshold, pts.view(M, 3), raw_gs, gsd)
+            vp, vf = c["pts"], c["feat"]
+            out["conf_valid"] = c["threshold"]
         else:
             vp, vf = pts.view(M, 3), raw_gs[:, :gsd]
         out["gaussians"] = ops.gaussian_adapter(vp, vf, self.sh_mask, cfg.sh_degree, cfg.opacity_exponent)
