@@ -1,6 +1,6 @@
 """Text -> 3DGS inference CLI — drop-in for /root/reference/inference_t23d.py (same flags, same output layout
-`<output_dir>/<prompt[:100] sans '/'>/{prompt.txt, gaussians.ply, gs.avi, depth.avi}` — the videos are Motion-JPEG AVI instead of
-the reference's mp4: no H.264 encoder exists in this image).
+`<output_dir>/<prompt[:100] sans '/'>/{prompt.txt, gaussians.ply, gs.mp4, depth.mp4}` — H.264 mp4 like the reference when imageio-ffmpeg
+or OpenCV is importable; in this image neither exists and the same frames are written as Motion-JPEG gs.avi / depth.avi).
 
     python -m torch.distributed.run --nproc_per_node=K --master-addr 127.0.0.1 inference_t23d.py --checkpoint_path ... \
         --transformer_lora_path ... --input_texts_path prompts.txt
@@ -46,6 +46,22 @@ def build_transformer(args, device):
     return WanDiT(cfg, sd, device=device)
 
 
+def build_text_encoder(args, device):
+    """(prompts, max_len) -> embeddings from `<model_id>/text_encoder` + `<model_id>/tokenizer` (the folders diffusers' WanPipeline
+    loads, /root/reference/inference_t23d.py:71-83), or None when they are not on disk (no hub access here)."""
+    te, tk = os.path.join(args.model_id, "text_encoder"), os.path.join(args.model_id, "tokenizer")
+    if not (os.path.isdir(te) and os.path.isdir(tk)):
+        return None
+    import glob
+    from safetensors.torch import load_file
+    from transformers import AutoTokenizer
+    from vist3a_amd.wan.text_encoder import UMT5Config, UMT5TextEncoder, make_pipeline_text_encoder
+    sd = {}
+    for f in sorted(glob.glob(os.path.join(te, "*.safetensors"))):
+        sd.update(load_file(f))
+    return make_pipeline_text_encoder(UMT5TextEncoder(UMT5Config(), sd, device=device), AutoTokenizer.from_pretrained(tk))
+
+
 def main(args):
     setup_dist()
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -65,13 +81,17 @@ def main(args):
         from vist3a_amd.wan.seqpar import DenoisePlan
         scene.pipe.plan = DenoisePlan.from_dist()
     embeds = torch.load(args.text_embeds_path, map_location="cpu") if args.text_embeds_path else None
+    encode = None if (embeds is not None or args.synthetic_text) else build_text_encoder(args, device)
     for prompt in prompts:
-        if embeds is not None:
+        if encode is not None:  # the reference's own route: WanPipeline.encode_prompt(prompt, negative_prompt), 512 tokens, zero padded
+            pe, ne = encode([PROMPT_TEMPLATE.format(prompt)], 512), encode([NEGATIVE_PROMPT], 512)
+        elif embeds is not None:
             pe, ne = embeds[PROMPT_TEMPLATE.format(prompt)][None].to(device), embeds["__negative__"][None].to(device)
         elif args.synthetic_text:
             pe, ne = synthetic_text_embeddings(device, seed=zlib.crc32(prompt.encode()) % (2 ** 31))
         else:
-            raise RuntimeError("no text encoder on this path: pass --text_embeds_path (precomputed UMT5 embeddings) or --synthetic_text")
+            raise RuntimeError(f"no text encoder: {args.model_id}/text_encoder + /tokenizer are not on disk (no hub access here); pass "
+                               "--text_embeds_path (precomputed UMT5 embeddings) or --synthetic_text")
         out, _, _ = scene.generate(pe, ne, generator=gen, num_frames=args.num_frames, num_inference_steps=args.num_inference_steps,
                                    guidance_scale=float(args.cfg_scale), height=args.resolution, width=args.resolution)
         if coop and rank != 0:

@@ -1,15 +1,14 @@
 import sys
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
 import torch
-from oracle import wan_dit as O
 from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
 from vist3a_amd.wan.pipeline import WanT2VPipeline
 from vist3a_amd.wan.scheduler import UniPCMultistepScheduler
 from vist3a_amd.wan.seqpar import DenoisePlan, ThreadWorld
 TINY = dict(num_attention_heads=2, attention_head_dim=128, ffn_dim=512, num_layers=2, text_dim=128, freq_dim=64)
-ocfg = O.WanDiTConfig(**TINY)
-sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=3).items()}
-model = WanDiT(WanDiTConfig(**TINY), sd, device="cuda")
+from vist3a_amd.wan.weights import random_dit_state_dict
+ocfg = WanDiTConfig(**TINY)
+model = WanDiT(ocfg, random_dit_state_dict(ocfg, seed=3, device="cuda"), device="cuda")
 g = torch.Generator().manual_seed(9)
 pe = torch.randn(1, 32, ocfg.text_dim, generator=g) * 0.5
 ne = torch.randn(1, 32, ocfg.text_dim, generator=g) * 0.5

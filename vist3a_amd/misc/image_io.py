@@ -1,8 +1,9 @@
 """Orbit video of a generated scene — `save_interpolated_video` / `save_video` of
 /root/reference/third_party_model/anysplat/src/misc/image_io.py:89-228 with the same arguments and the same frames.
 
-Container: the reference writes H.264 mp4 through imageio-ffmpeg; neither an encoder nor imageio exists in this image, so the
-frames go into a Motion-JPEG AVI (`gs.avi`, `depth.avi`; PIL encodes each frame) — same frame count, order, size and fps."""
+Container: the reference writes H.264 `gs.mp4` / `depth.mp4` through imageio-ffmpeg.  `save_video` does the same whenever
+imageio(+ffmpeg) or OpenCV is importable; in this image neither exists, and the frames go into a Motion-JPEG AVI with the same
+stem (`gs.avi`, `depth.avi`; PIL encodes each frame) — same frame count, order, size and fps."""
 from __future__ import annotations
 
 import io
@@ -38,18 +39,52 @@ def interpolate_camera_path(pred_extrinsics: torch.Tensor, pred_intrinsics: torc
     return torch.cat(ex, dim=1), torch.cat(ix, dim=1)
 
 
-def save_video(video: Union[torch.Tensor, np.ndarray], save_path: Union[str, Path], fps: int = 20, quality: int = 92) -> None:
-    """video [T,3,H,W] in [0,1] (or uint8 [T,H,W,3]) -> Motion-JPEG AVI."""
-    from PIL import Image
+def _h264_writer():
+    """An H.264/mp4 writer if one is importable (what the reference uses: imageio + imageio-ffmpeg, src/misc/image_io.py:217-228;
+    else OpenCV); None in this image, where neither exists."""
+    try:
+        import imageio.v2 as imageio  # noqa: F401
+        import imageio_ffmpeg  # noqa: F401
+        return "imageio"
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        import cv2  # noqa: F401
+        return "cv2"
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def save_video(video: Union[torch.Tensor, np.ndarray], save_path: Union[str, Path], fps: int = 20, quality: int = 92) -> str:
+    """video [T,3,H,W] in [0,1] (or uint8 [T,H,W,3]) -> `<save_path>` as H.264 mp4 when an encoder is importable (the reference's
+    container, consumed by evaluation/gen_eval/utils.py:43-53), otherwise the same frames as a Motion-JPEG AVI next to it
+    (`.avi` suffix).  Returns the path actually written."""
     if isinstance(video, torch.Tensor):
         video = (video.detach().float().clamp(0, 1).permute(0, 2, 3, 1).cpu().numpy() * 255).astype(np.uint8)
     T, H, W, _ = video.shape
+    save_path = Path(save_path)
+    enc = _h264_writer()
+    if enc == "imageio":
+        import imageio.v2 as imageio
+        with imageio.get_writer(str(save_path.with_suffix(".mp4")), fps=fps, codec="libx264", macro_block_size=1) as wr:
+            for f in video:
+                wr.append_data(f)
+        return str(save_path.with_suffix(".mp4"))
+    if enc == "cv2":
+        import cv2
+        wr = cv2.VideoWriter(str(save_path.with_suffix(".mp4")), cv2.VideoWriter_fourcc(*"mp4v"), fps, (W, H))
+        for f in video:
+            wr.write(f[..., ::-1].copy())
+        wr.release()
+        return str(save_path.with_suffix(".mp4"))
+    from PIL import Image
     frames = []
     for f in video:
         buf = io.BytesIO()
         Image.fromarray(f).save(buf, format="JPEG", quality=quality)
         frames.append(buf.getvalue())
-    _write_mjpeg_avi(Path(save_path), frames, W, H, fps)
+    _write_mjpeg_avi(save_path.with_suffix(".avi"), frames, W, H, fps)
+    return str(save_path.with_suffix(".avi"))
 
 
 def _chunk(tag: bytes, data: bytes) -> bytes:
@@ -93,7 +128,6 @@ def save_interpolated_video(pred_extrinsics, pred_intrinsics, b, h, w, gaussians
     col = matplotlib.colormaps["turbo"](dn)[..., :3]
     depth_colored = torch.from_numpy(col).permute(0, 3, 1, 2).clip(min=0, max=1)
     stem_c, stem_d = ("gs", "depth") if name is None else ("gs_optimized", "gs_optimized_depth")
-    pc, pd = os.path.join(save_path, f"{stem_c}.avi"), os.path.join(save_path, f"{stem_d}.avi")
-    save_video(depth_colored, pd, fps=20)
-    save_video(video, pc, fps=20)
+    pd = save_video(depth_colored, os.path.join(save_path, f"{stem_d}.mp4"), fps=20)
+    pc = save_video(video, os.path.join(save_path, f"{stem_c}.mp4"), fps=20)
     return pc, pd

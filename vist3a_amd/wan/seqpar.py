@@ -1,5 +1,5 @@
-"""Multi-GPU decomposition of ONE denoise (latency mode, BASELINE.json configs #3/#4 — the `xfuser` Ulysses/USP option of
-/root/reference/third_party_model/Wan2_1/wan/distributed/xdit_context_parallel.py, re-thought for xGMI).
+"""Multi-GPU decomposition of ONE denoise (latency mode, BASELINE.json configs #3/#4).  The reference has no sequence-parallel
+inference path (its ranks only stride the prompt list, /root/reference/inference_t23d.py:62); this is new, designed for xGMI.
 
 The throughput path needs no collective (ranks stride the prompt list, utils/dist_util.py).  When a single scene must
 finish sooner, the 50-step loop is split two ways:
