@@ -47,27 +47,65 @@ def dit_flops_per_forward(N, d, ffn, L, ctx=512):
     return L * (8 * N * d * d + 4 * N * N * d + (4 * N * d * d + 4 * ctx * d * d) + 4 * N * ctx * d + 4 * N * d * ffn)
 
 
-def cpu_baseline(cfg, seconds_budget: float):
-    """Oracle (CPU fp32 restatement) timed on the host cores on a bounded sample: ONE full-size (N=4096, B=1) DiT forward
-    restricted to 2 of the 30 blocks; extrapolated to 30 blocks x 100 forwards.  VAE+recon (5 % of the FLOPs) excluded."""
+def cpu_baseline(cfg, mode: str):
+    """The CPU oracle (fp32 restatement of the reference path, `kind: "port"`) timed ONCE on this host's cores, stage by stage, at
+    the production shapes of config #1/#2: one full 30-block DiT forward (N = 4096 tokens, B = 1), one Wan VAE
+    decode (latent [1,16,4,64,64] -> 13 x 512^2) and one stitched reconstruction forward (13 views @448, 22 DINO + 48 aggregator
+    blocks at width 1024, heads, voxel fusion).  A scene is 2 x steps DiT forwards + one decode + one reconstruction: only that
+    multiplication is extrapolated.  mode = "full" (about 2-3 minutes of CPU) | "dit" (the DiT forward only, ~40 s)."""
+    from oracle import recon as R
     from oracle import wan_dit as O
-    ocfg = O.WanDiTConfig(num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim, ffn_dim=cfg.ffn_dim,
-                          num_layers=2, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim)
-    sd = O.make_weights(ocfg, seed=0)
+    from oracle import wan_vae as V
+    n = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
+    ocfg = O.WanDiTConfig(num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim, ffn_dim=cfg.ffn_dim,
+                          num_layers=cfg.num_layers, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim)
+    sd = O.make_weights(ocfg, seed=0)
     lat = torch.randn(1, 16, 4, 64, 64, generator=g)
     text = torch.randn(1, 512, cfg.text_dim, generator=g) * 0.1
     t = torch.tensor([900])
+    stages = {}
     with torch.no_grad():
-        O.dit_forward(sd, ocfg, lat[:, :, :1], t, text)  # warm the thread pool on a small clip
+        O.dit_forward(sd, ocfg, lat[:, :, :1, :16, :16], t, text, num_layers=1)  # warm the thread pool on a small clip
         t0 = time.perf_counter()
         O.dit_forward(sd, ocfg, lat, t, text)
-        dt = time.perf_counter() - t0
-    per_block = dt / 2
-    scene_s = per_block * cfg.num_layers * 100
-    return dict(value=1.0 / scene_s, unit="scenes/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle WanDiT fp32, N=4096 B=1, 2 of {cfg.num_layers} blocks in {dt:.2f}s; scene = {cfg.num_layers} blocks x 100 forwards "
-                       f"(extrapolated, {scene_s:.0f}s/scene); VAE decode + reconstruction (5% of FLOPs) not included")
+        stages["dit_forward_s"] = time.perf_counter() - t0
+        del sd
+        if mode == "full":
+            vcfg = V.WanVAEConfig()
+            vsd = V.make_weights(vcfg, seed=1)
+            t0 = time.perf_counter()
+            img = V.decode(vsd, vcfg, lat)
+            stages["vae_decode_s"] = time.perf_counter() - t0
+            del vsd
+            rcfg = R.ReconCfg()
+            rsd = R.make_recon_weights(rcfg, seed=2)
+            w = torch.randn(rcfg.C, 16, 5, 3, 3, generator=g) * 0.02
+            img448 = torch.nn.functional.interpolate(img[0].permute(1, 0, 2, 3).clamp(-1, 1), size=(448, 448), mode="bilinear", align_corners=False)
+            img448 = img448.permute(1, 0, 2, 3)[None]
+            t0 = time.perf_counter()
+            feat = R.stitch_conv(R.upsample_T(lat), w, torch.zeros(rcfg.C), (1, 2, 2), (2, 1, 1))
+            R.recon_forward(rsd, rcfg, feat, img448)
+            stages["stitch_recon_s"] = time.perf_counter() - t0
+            del rsd
+    tail = stages.get("vae_decode_s", 0.0) + stages.get("stitch_recon_s", 0.0)
+    scene50 = 100 * stages["dit_forward_s"] + tail
+    scene10 = 20 * stages["dit_forward_s"] + tail
+    what = ("one full DiT forward + one VAE decode + one reconstruction forward" if mode == "full" else
+            "one full DiT forward; VAE decode + reconstruction (5 % of the FLOPs) not timed")
+    return dict(value=1.0 / scene50, unit="scenes/s", cores=n, kind="port",
+                sample=f"oracle fp32 on {n} threads, production shapes, each stage timed once: {what}; scene = 100 x DiT + decode + recon "
+                       f"(only the x100 is extrapolated)",
+                stage_seconds={k: round(v, 2) for k, v in stages.items()},
+                scene_seconds_50_steps=round(scene50, 1),
+                config1_10_steps={"scene_seconds": round(scene10, 1), "scenes_per_s": 1.0 / scene10,
+                                  "note": "BASELINE config #1 (10 denoise steps) = 20 x DiT + decode + recon"})
+
+
+def dit_flops_executed(N, d, ffn, L, ctx_keys: int):
+    """FLOPs the product actually executes per forward: the text context K / V^T projections are cached per prompt (not per step),
+    and cross-attention runs over the `ctx_keys` real + merged-padding keys instead of 512."""
+    return L * (8 * N * d * d + 4 * N * N * d + 4 * N * d * d + 4 * N * ctx_keys * d + 4 * N * d * ffn)
 
 
 def main():
@@ -77,7 +115,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--denoise-steps", type=int, default=50)
     ap.add_argument("--num-frames", type=int, default=13)
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-baseline", choices=["full", "dit", "none"], default="full",
+                    help="CPU oracle timed once per stage on this host (full: ~2-3 min of CPU after the timed GPU region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parallel", choices=["dp", "scene"], default="dp",
                     help="dp: one prompt per GPU, no data-path collective (the reference's split; the headline metric). "
@@ -160,10 +199,39 @@ def main():
             dec.forward(out.gaussians, ex, ix.float(), ones * 0.1, ones * 100, (448, 448))
             torch.cuda.synchronize()
             render_ms = (time.perf_counter() - tr) * 1e3
+    # R13 / R15 / rasteriser at a REALISTIC point distribution (untimed extra): seeded synthetic weights collapse the 2.6 M points of
+    # a scene into ~35 k voxels (near-constant depth, near-identical poses); real checkpoints keep 1-2 M.  Same kernels, a spread cloud.
+    tail = None
+    if rank == 0:
+        from vist3a_amd.models.types import Gaussians
+        gen = torch.Generator(device=dev).manual_seed(7)
+        M = a.num_frames * 448 * 448
+        pts = torch.randn(M, 3, device=dev, generator=gen) * 0.25
+        pts[:, 2] += 1.5
+        raw = torch.randn(M, 84, device=dev, generator=gen) * 0.5
+        eng = model.stitched_decoder.stitched_3d_model.engine()
+
+        def timed(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - tq) / reps * 1e3, r
+
+        vox_ms, v = timed(lambda: ops.voxelize_fuse(pts, raw, 83, 83, 0.002))
+        ad_ms, gs = timed(lambda: ops.gaussian_adapter(v["voxel_pts"], v["voxel_feat"], eng.sh_mask, 4, 1.0))
+        gsp = Gaussians(**{k: t[None] for k, t in gs.items()})
+        rd_ms, _ = timed(lambda: dec.forward(gsp, ex, ix.float(), ones * 0.1, ones * 100, (448, 448)), reps=1)
+        tail = {"points": M, "voxels": int(v["keys"].shape[0]), "voxelize+fuse_ms": round(vox_ms, 2), "gaussian_adapter_ms": round(ad_ms, 2),
+                "orbit_render_ms_132_cameras_448": round(rd_ms, 1)}
+        del pts, raw, v, gs, gsp
     if rank == 0:
         ps = probe.summary()
         ach = ps["flops_per_launch"] / (ps["avg_ms"] * 1e-3) / 1e12 if ps["launches"] else 0.0
         fwd_flops = dit_flops_per_forward(N, cfg.dim, cfg.ffn_dim, cfg.num_layers)
+        ctx_keys = (64 + 1 + 80 + 1) // 2   # synthetic prompts: 64 / 80 real tokens + one merged padding key each (cond / uncond)
         U = int(out.gaussians.means.shape[1])
         line = {
             "metric": "3D Gaussian scenes/sec (50-step denoise, 512^2, 13 views)",
@@ -177,15 +245,20 @@ def main():
                        "stage_ms_last_scene": {"denoise": round(stage.denoise_ms, 1), "vae_decode+resize": round(stage.vae_ms, 1),
                                                "stitch+recon": round(stage.recon_ms, 1)},
                        "orbit_render_ms_132_cameras_448 (untimed extra)": round(render_ms, 1),
-                       "dit_model_tflops_per_s": round(2 * a.denoise_steps * fwd_flops / (stage.denoise_ms * 1e-3) / 1e12, 1)},
+                       "recon_tail_on_spread_cloud (untimed extra)": tail,
+                       "dit_model_tflops_per_s": round(2 * a.denoise_steps * fwd_flops / (stage.denoise_ms * 1e-3) / 1e12, 1),
+                       "dit_executed_tflops_per_s": round(2 * a.denoise_steps * dit_flops_executed(N, cfg.dim, cfg.ffn_dim, cfg.num_layers, ctx_keys)
+                                                          / (stage.denoise_ms * 1e-3) / 1e12, 1),
+                       "dit_flops_note": f"model = BASELINE.md §2 formula (512 text keys, context K/V projected every step); executed = "
+                                         f"{ctx_keys} cross-attention keys after merging the zero-padding keys, context K/V cached per prompt"},
             "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<{lib.load().v3a_gemm_tile_name(dom_tile).decode()}> (bf16 MFMA 32x32x16)",
                          "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic("gemm_nt_kernel<256,192,4,2,64,2,false,0"), "traffic_unit": "bytes/launch (PMC, profiles/)",
                          "launches_timed": ps["launches"], "avg_launch_ms": round(ps["avg_ms"], 4),
                          "flops_per_launch": ps["flops_per_launch"]},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline_seconds)
+        if world == 1 and not a.no_cpu_baseline and a.cpu_baseline != "none":
+            line["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -181,35 +181,43 @@ struct AdP {
   const float* shmask;
   float* means; float* cov; float* sh; float* opac; float* scales; float* rot;
 };
+// One 16-LANE GROUP per Gaussian: the 83-float input row and the 75-float SH output row are moved as coalesced 64-byte pieces
+// (a wave's four Gaussians are adjacent rows, i.e. one contiguous 1.2 KB output span); the 8 leading scalars are broadcast inside
+// the group and the tiny per-Gaussian algebra (opacity, softplus scales, quaternion -> R, covariance) is done redundantly by every
+// lane.  The thread-per-Gaussian form read and wrote rows at a 300-byte stride per lane: 10.7 ms for 2.6 M Gaussians.
 __global__ __launch_bounds__(256) void gaussian_adapter_kernel(const AdP p) {
-  const long u = (long)blockIdx.x * 256 + threadIdx.x;
-  if (u >= p.U) return;
+  const int lane = threadIdx.x & 63, sl = lane & 15, gbase = lane & 48;
+  const long u = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  if (u >= p.U) return;   // whole groups leave together
   const float* f = p.feats + (size_t)u * p.ldf;
+  const float head = sl < 8 ? f[sl] : 0.f;
+  float h[8];
 #pragma unroll
-  for (int e = 0; e < 3; ++e) p.means[u * 3 + e] = p.pts[u * 3 + e];
-  const float pd = 1.f / (1.f + expf(-f[0]));
+  for (int e = 0; e < 8; ++e) h[e] = __shfl(head, gbase + e, 64);
+  if (sl < 3) p.means[u * 3 + sl] = p.pts[u * 3 + sl];
+  const float pd = 1.f / (1.f + expf(-h[0]));
   const float ex = p.op_exp;
-  p.opac[u] = 0.5f * (1.f - (ex == 1.f ? (1.f - pd) : powf(1.f - pd, ex)) + (ex == 1.f ? pd : powf(pd, 1.f / ex)));
+  if (sl == 0) p.opac[u] = 0.5f * (1.f - (ex == 1.f ? (1.f - pd) : powf(1.f - pd, ex)) + (ex == 1.f ? pd : powf(pd, 1.f / ex)));
   float s[3], q[4];
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    const float x = f[1 + e];
+    const float x = h[1 + e];
     const float sp = x > 20.f ? x : log1pf(expf(x));  // F.softplus (beta=1, threshold=20)
     s[e] = fminf(0.001f * sp, 0.3f);
-    p.scales[u * 3 + e] = s[e];
   }
   float n2 = 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { q[e] = f[4 + e]; n2 += q[e] * q[e]; }
+  for (int e = 0; e < 4; ++e) { q[e] = h[4 + e]; n2 += q[e] * q[e]; }
   const float inv = 1.f / (sqrtf(n2) + 1e-8f);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { q[e] *= inv; p.rot[u * 4 + e] = q[e]; }
+  for (int e = 0; e < 4; ++e) q[e] *= inv;
   const float i = q[0], j = q[1], k = q[2], r = q[3];
   const float two_s = 2.0f / (i * i + j * j + k * k + r * r);
   const float R[9] = {1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
                       two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
                       two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)};
-  // cov = R diag(s) diag(s)^T R^T
+  // cov = R diag(s) diag(s)^T R^T; lane sl < 9 stores element sl
+  float mine = 0.f, sc = 0.f, rt = 0.f;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -217,10 +225,19 @@ __global__ __launch_bounds__(256) void gaussian_adapter_kernel(const AdP p) {
       float acc = 0.f;
 #pragma unroll
       for (int m = 0; m < 3; ++m) acc += (R[a * 3 + m] * s[m]) * s[m] * R[b * 3 + m];
-      p.cov[u * 9 + a * 3 + b] = acc;
+      if (sl == a * 3 + b) mine = acc;
     }
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+    if (sl == e) sc = s[e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (sl == e) rt = q[e];
+  if (sl < 9) p.cov[u * 9 + sl] = mine;
+  if (sl < 3) p.scales[u * 3 + sl] = sc;
+  if (sl < 4) p.rot[u * 4 + sl] = rt;
   const int nsh = 3 * p.dsh;
-  for (int e = 0; e < nsh; ++e) p.sh[(size_t)u * nsh + e] = f[8 + e] * p.shmask[e % p.dsh];
+  for (int e = sl; e < nsh; e += 16) p.sh[(size_t)u * nsh + e] = f[8 + e] * p.shmask[e % p.dsh];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -354,7 +371,7 @@ extern "C" int v3a_gaussian_adapter(const float* pts, const float* feats, int ld
   const int dsh = (sh_degree + 1) * (sh_degree + 1);
   if (U <= 0 || ldf < 8 + 3 * dsh) return V3A_ERR_SHAPE;
   AdP p{pts, feats, ldf, U, dsh, opacity_exponent, sh_mask, means, cov, sh, opac, scales, rot};
-  hipLaunchKernelGGL(gaussian_adapter_kernel, dim3(nblk(U)), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(gaussian_adapter_kernel, dim3((unsigned)((U * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
   return LAUNCH_OK();
 }
 
