@@ -487,10 +487,14 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
       }
     }
     l_run = l_run * alpha + psum;
+    // the running maximum settles after the first few tiles: skip the 64 accumulator multiplies while no lane's maximum moved
+    // (alpha == 1 exactly then, so the result is bit-identical to always rescaling)
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-    for (int i = 0; i < DT; ++i)
+      for (int i = 0; i < DT; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
     // V^T pieces were issued before the K pieces: leave the K prefetch in flight
     if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

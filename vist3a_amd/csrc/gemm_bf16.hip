@@ -75,6 +75,16 @@ struct TileCfg {
   static_assert(BM % 32 == 0, "swizzle assumes B rows start at a multiple of 32");
 };
 
+// Under load (every CU streaming) a global load issued in the epilogue takes MICROSECONDS to come back, and nothing is left to hide
+// it: an exposed bias load cost FFN1 30 us, more than the rest of its epilogue.  The ping-pong kernel therefore DMAs the tile's
+// bias / gate-scale slices into LDS before its K loop (the oldest vector-memory operations of the wave: the counted waits of the
+// main loop cover them) and the epilogue reads them from there.
+struct EpiAux {
+  const char* lds_bias = nullptr;    // f32 [tile columns] (or [tile rows] with BIAS_ROW), indexed relative to n0 (m0)
+  const char* lds_scale = nullptr;   // f32 [tile columns] of the tile's (single) batch row of `scale`
+  int m0 = 0, n0 = 0;
+};
+
 // Epilogue shared by every main loop: the wave owns an (MT*32) x (NTL*32) output tile whose 32x32 blocks sit in acc[i][j] in
 // D^T orientation (lane (l31, hi) holds rows m = l31, 4 consecutive columns per accumulator quad).  Per 32-row group:
 //   phase 1: acc (bias already added by gemm_add_bias) -> bf16 -> this wave's private
@@ -86,7 +96,7 @@ struct TileCfg {
 // hides under the convert-and-park work (not with a 128-register accumulator, where it would spill).
 template <int ACT, int MT, int NTL, int PFB, bool EARLY, int DBG>
 __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane,
-                                                  int mw0, int nw) {
+                                                  int mw0, int nw, const EpiAux& aux) {
   constexpr int WTN = NTL * 32, PITCH = WTN * 2 + 8;
   if constexpr (DBG & 2) {   // development ablation: no epilogue at all (accumulators kept live)
 #pragma unroll
@@ -116,8 +126,8 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
   auto fetch = [&](int mw, int it, int s) {
     int m, n, ml, ch;
     coords(mw, it, m, n, ml, ch);
-    if (m >= p.M || n >= p.N) return;
-    if (p.scale) {
+    m = min(m, p.M - 1); n = min(n, p.N - 8);   // out-of-range chunks read a valid address and are dropped at the store: no
+    if (p.scale && !aux.lds_scale) {            // divergent branch around the loads (hipcc serialises loads under exec masks)
       const float* sp = p.scale + ((flags & V3A_GEMM_SCALE_PER_BATCH) ? (size_t)(m / p.rpb) * p.sstride : 0) + n;
       ps0[s] = *(const f32x4*)sp; ps1[s] = *(const f32x4*)(sp + 4);
     }
@@ -150,6 +160,7 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if constexpr (DBG & 4) continue;   // development ablation: park only
 #pragma unroll
     for (int it0 = 0; it0 < ITERS; it0 += PB) {
       if (!EARLY || it0 > 0) {
@@ -162,7 +173,7 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
         coords(mw, it0 + s, m, n, ml, ch);
         const u32x2 lo = *(const u32x2*)(reg + ml * PITCH + ch * 16);
         const u32x2 hi2 = *(const u32x2*)(reg + ml * PITCH + ch * 16 + 8);
-        if (m >= p.M || n >= p.N) continue;
+        const bool inside = m < p.M && n < p.N;
         u32x4 raw;
         raw[0] = lo[0]; raw[1] = lo[1]; raw[2] = hi2[0]; raw[3] = hi2[1];
         float v[8];
@@ -179,6 +190,10 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
           }
         }
         if (p.scale) {
+          if (aux.lds_scale) {
+            const char* sp = aux.lds_scale + (min(n, p.N - 8) - aux.n0) * 4;
+            ps0[s] = *(const f32x4*)sp; ps1[s] = *(const f32x4*)(sp + 16);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] *= ps0[s][e]; v[4 + e] *= ps1[s][e]; }
           if (flags & V3A_GEMM_ROUND_AFTER_SCALE) {
@@ -198,7 +213,7 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
           }
         }
         if (p.res2) {
-          const u32x4 rr = *(const u32x4*)(p.res2 + ((size_t)m * p.ldr2 + n) * 2);
+          const u32x4 rr = *(const u32x4*)(p.res2 + ((size_t)min(m, p.M - 1) * p.ldr2 + min(n, p.N - 8)) * 2);
           float rf[8];
           unpack_bf16x8(rr, rf);
 #pragma unroll
@@ -218,10 +233,13 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
           f32x4 o0, o1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
-          *(f32x4*)cp = o0;
-          *(f32x4*)(cp + 4) = o1;
+          if (inside) {
+            *(f32x4*)cp = o0;
+            *(f32x4*)(cp + 4) = o1;
+          }
         } else {
-          *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = pack_bf16x8(v);
+          const u32x4 o = pack_bf16x8(v);
+          if (inside) *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = o;
         }
       }
     }
@@ -235,27 +253,28 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
 // even ReLU, cost FFN1 +70 us.
 template <int MT, int NTL, int PFB, bool EARLY, int DBG = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane,
-                                              int mw0, int nw) {
+                                              int mw0, int nw, const EpiAux& aux = EpiAux{}) {
   switch (p.act) {
-    case V3A_ACT_GELU_TANH: gemm_epilogue_act<V3A_ACT_GELU_TANH, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
-    case V3A_ACT_GELU_ERF: gemm_epilogue_act<V3A_ACT_GELU_ERF, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
-    case V3A_ACT_SILU: gemm_epilogue_act<V3A_ACT_SILU, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
-    case V3A_ACT_RELU: gemm_epilogue_act<V3A_ACT_RELU, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
-    default: gemm_epilogue_act<V3A_ACT_NONE, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw); break;
+    case V3A_ACT_GELU_TANH: gemm_epilogue_act<V3A_ACT_GELU_TANH, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw, aux); break;
+    case V3A_ACT_GELU_ERF: gemm_epilogue_act<V3A_ACT_GELU_ERF, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw, aux); break;
+    case V3A_ACT_SILU: gemm_epilogue_act<V3A_ACT_SILU, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw, aux); break;
+    case V3A_ACT_RELU: gemm_epilogue_act<V3A_ACT_RELU, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw, aux); break;
+    default: gemm_epilogue_act<V3A_ACT_NONE, MT, NTL, PFB, EARLY, DBG>(p, acc, smem, wave, lane, mw0, nw, aux); break;
   }
 }
 
 // acc += bias (fp32), ahead of the epilogue: all bias loads of the wave tile are issued together (one exposed latency instead of
 // one per accumulator quad) and only once, since the column bias is the same for every 32-row group.
 template <int MT, int NTL>
-__device__ __forceinline__ void gemm_add_bias(const GemmP& p, f32x16 (&acc)[MT][NTL], int lane, int mw0, int nw) {
+__device__ __forceinline__ void gemm_add_bias(const GemmP& p, f32x16 (&acc)[MT][NTL], int lane, int mw0, int nw,
+                                              const EpiAux& aux = EpiAux{}) {
   const int hi = lane >> 5, l31 = lane & 31;
   if (!p.bias) return;
   if (p.flags & V3A_GEMM_BIAS_ROW) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int m = mw0 + i * 32 + l31;
-      const float b = p.bias[m < p.M ? m : p.M - 1];
+      const int m = min(mw0 + i * 32 + l31, p.M - 1);
+      const float b = aux.lds_bias ? *(const float*)(aux.lds_bias + (m - aux.m0) * 4) : p.bias[m];
 #pragma unroll
       for (int j = 0; j < NTL; ++j)
 #pragma unroll
@@ -267,12 +286,11 @@ __device__ __forceinline__ void gemm_add_bias(const GemmP& p, f32x16 (&acc)[MT][
     for (int j = 0; j < NTL; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = nw + j * 32 + g * 8 + hi * 4;
-        if (n + 3 < p.N) bq[j][g] = *(const f32x4*)(p.bias + n);
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bq[j][g][e] = n + e < p.N ? p.bias[n + e] : 0.f;
-        }
+        // N % 8 == 0 and n % 4 == 0: a quad is either entirely inside [0, N) or entirely outside (and then never stored), so
+        // the load is made branch-free by clamping its address.  (With a per-quad `if` hipcc wrapped every load in exec-mask
+        // control flow and waited for each one in turn: 12 serial L2 round trips, 5 us per tile.)
+        const int n = min(nw + j * 32 + g * 8 + hi * 4, p.N - 4);
+        bq[j][g] = aux.lds_bias ? *(const f32x4*)(aux.lds_bias + (n - aux.n0) * 4) : *(const f32x4*)(p.bias + n);
       }
 #pragma unroll
     for (int j = 0; j < NTL; ++j)
@@ -574,7 +592,8 @@ struct PPCfg {
     return (rem >= 3 || steady < tail) ? steady : tail;
   }
   static constexpr int EPI_BYTES = 8 * 32 * (128 * 2 + 8);
-  static constexpr int LDS_BYTES = 2 * STAGE;
+  static constexpr int AUX = 2 * STAGE;              // 1 KiB bias slice + 1 KiB gate-scale slice of the tile, behind the ring
+  static constexpr int LDS_BYTES = 2 * STAGE + 2048;
   static_assert(J == cum(NP), "chunking");
   static_assert(LDS_BYTES >= EPI_BYTES, "epilogue parks in the ring");
 };
@@ -734,6 +753,26 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
 
   int m0, n0;
   setup(blockIdx.x, m0, n0);
+  // ---- bias / gate-scale slices of this tile -> LDS (oldest DMAs of the wave: every later counted wait covers them) ----
+  EpiAux aux;
+  aux.m0 = m0; aux.n0 = n0;
+  {
+    const bool brow = (p.flags & V3A_GEMM_BIAS_ROW) != 0;
+    const int blim = brow ? p.M : p.N;
+    if (p.bias && blim % 4 == 0) {   // (a ragged BIAS_ROW extent keeps the global loads: a clamped 16-B piece would shift it)
+      aux.lds_bias = smem + T::AUX;
+      // 256 floats cover a tile edge; lanes clamped at the end of the vector hold columns / rows that are never stored
+      if (wave == 0) glds16(p.bias + min((brow ? m0 : n0) + lane * 4, blim - 4), smem + T::AUX);
+    }
+    if (p.scale) {
+      const int b0 = (p.flags & V3A_GEMM_SCALE_PER_BATCH) ? m0 / p.rpb : 0;
+      const int b1 = (p.flags & V3A_GEMM_SCALE_PER_BATCH) ? min(m0 + BM - 1, p.M - 1) / p.rpb : 0;
+      if (b0 == b1) {   // the tile lies inside one batch item (always, when rows_per_batch % BM == 0): one 1-KiB slice
+        aux.lds_scale = smem + T::AUX + 1024;
+        if (wave == 1) glds16(p.scale + (size_t)b0 * p.sstride + min(n0 + lane * 4, p.N - 4), smem + T::AUX + 1024);
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -797,8 +836,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     // every fragment read has returned (lgkmcnt(0) precedes the last MFMAs) and no DMA is in flight (the tail waits reach 0):
     // both stages are free
     const int em = m0 + (RA ? wr * 64 : ws * 32 * NP), en = n0 + (RA ? ws * 32 * NP : wr * 64);
-    if constexpr (!(ABL & 32)) gemm_add_bias<MT, NTL>(p, acc, lane, em, en);
-    gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8), (ABL >> 4) & 3>(p, acc, smem, wave, lane, em, en);
+    if constexpr (!(ABL & 32) && !(ABL & 128)) gemm_add_bias<MT, NTL>(p, acc, lane, em, en, aux);
+    gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8), (ABL >> 4) & 15>(p, acc, smem, wave, lane, em, en, aux);
   }
 }
 
@@ -839,7 +878,7 @@ const TileEntry kTiles[] = {
     PP_ENTRY(3, false, 5),   // 8: 192x256 (V^T = Wv . X^T)
 #ifdef V3A_GEMM_ABL
     PP_ABL(4, true, 7, 1), PP_ABL(4, true, 7, 2), PP_ABL(4, true, 7, 3), PP_ABL(4, true, 7, 4), PP_ABL(4, true, 7, 5), PP_ABL(4, true, 7, 6),
-    PP_ABL(3, true, 5, 1), PP_ABL(3, true, 5, 3), PP_ABL(3, true, 5, 4), PP_ABL(3, true, 5, 16), PP_ABL(3, true, 5, 32),
+    PP_ABL(3, true, 5, 1), PP_ABL(3, true, 5, 3), PP_ABL(3, true, 5, 4), PP_ABL(3, true, 5, 16), PP_ABL(3, true, 5, 32), PP_ABL(3, true, 5, 64), PP_ABL(3, true, 5, 128), PP_ABL(3, true, 5, 192),
 #endif
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
