@@ -118,6 +118,10 @@ def main():
     ap.add_argument("--cpu-baseline", choices=["full", "dit", "none"], default="full",
                     help="CPU oracle timed once per stage on this host (full: ~2-3 min of CPU after the timed GPU region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--model", choices=["1.3b", "14b"], default="1.3b",
+                    help="14b = BASELINE config #4 geometry (Wan-14B, 40 x 128 heads, FFN 13824, 40 blocks); NOT the headline config")
+    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8: DiT self-attention on the block-scaled e4m3 MFMA (config #4's precision mode); GEMMs stay bf16")
     ap.add_argument("--parallel", choices=["dp", "scene"], default="dp",
                     help="dp: one prompt per GPU, no data-path collective (the reference's split; the headline metric). "
                          "scene: all ranks cooperate on ONE scene (CFG-parallel x sequence-parallel DiT over RCCL; latency mode)")
@@ -138,10 +142,11 @@ def main():
     from vist3a_amd import ops
     from vist3a_amd import lib
     from vist3a_amd.t23d import SceneTimes, Text23DGS, synthetic_text_embeddings
-    from vist3a_amd.wan.dit import WAN_1_3B
+    from vist3a_amd.wan.dit import WAN_1_3B, WAN_14B
     lib.load()
-    cfg = WAN_1_3B
+    cfg = WAN_14B if a.model == "14b" else WAN_1_3B
     model = Text23DGS.synthetic(cfg, seed=0, device=dev)
+    model.transformer.attn_dtype = a.dtype
     pe, ne = synthetic_text_embeddings(dev)
     coop = a.parallel == "scene" and world > 1
     if coop:
@@ -237,8 +242,9 @@ def main():
             "metric": "3D Gaussian scenes/sec (50-step denoise, 512^2, 13 views)",
             "value": (1 if coop else world) * a.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if coop else "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (seeded random weights of production shapes, synthetic text embeddings)",
-            "config": {"workload": f"Wan-1.3B stitched, {a.denoise_steps}-step CFG denoise (batch-2 cond/uncond), {a.num_frames} views @512, "
+            "dtype": a.dtype if a.dtype == "bf16" else "fp8 (e4m3 self-attention operands; bf16 GEMMs)",
+            "data": "synthetic (seeded random weights of production shapes, synthetic text embeddings)",
+            "config": {"workload": f"Wan-{'14B' if a.model == '14b' else '1.3B'} stitched, {a.denoise_steps}-step CFG denoise (batch-2 cond/uncond), {a.num_frames} views @512, "
                                    "VAE decode, 448^2 AnySplat enc_blocks_2 reconstruction with voxel fusion; "
                                    + ("one scene over all GPUs (CFG-parallel x sequence-parallel)" if coop else "1 prompt per GPU (data parallel)"),
                        "denoise_steps": a.denoise_steps, "views": a.num_frames, "dit_tokens": N, "gaussians_last_scene": U,

@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 7) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 8) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -128,6 +128,26 @@ typedef struct {
   int key_bias_first;       /* keys < key_bias_first have zero bias (their tiles skip the bias loads); 0 = any key may carry bias */
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3) flash attention forward on the block-scaled MFMA (K = 64, twice the bf16 rate): the self-attention launch of
+ * BASELINE config #4 (Wan-14B; model choice at /root/reference/utils/argument.py:399, /root/reference/inference_t23d.py:73).
+ * The reference computes this attention in bf16 (F.scaled_dot_product_attention under autocast): this entry is an opt-in
+ * precision mode whose rounding points are pinned by the oracle's e4m3 emulation (oracle/wan_dit.py attention_fp8_emulated).
+ * q, k: e4m3 bytes [B][N][H*128] (row stride ld* BYTES); vt: e4m3 bytes [H*128][B*vt_batch_stride + key], readable up to the next
+ * multiple of 64 keys; o: bf16.  Stored values are x / *_scale; D must be 128.
+ * v3a_quantize_fp8: y[r][c] = e4m3(x[r][c] / scale), RNE, clamped to +-448; x bf16 [rows][ldx], y bytes [rows][ldy], cols % 16 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q; const void* k; const void* vt; void* o;
+  long q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride;   /* elements of the respective tensor */
+  int ldq, ldk, ldvt, ldo;
+  int B, H, Nq, Nk, D;
+  float scale;                      /* softmax scale, normally D^-0.5 */
+  float q_scale, k_scale, v_scale;  /* per-tensor quantisation scales */
+} v3a_attn_fp8_args;
+int v3a_attention_fwd_fp8(const v3a_attn_fp8_args* args, void* stream);
+int v3a_quantize_fp8(const void* x, void* y, long rows, int cols, int ldx, int ldy, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm in fp32 (+ optional affine) (+ optional AdaLN modulation  y = LN(x)*(1+scale[b])+shift[b]).

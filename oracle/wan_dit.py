@@ -125,7 +125,7 @@ def condition_embed(sd, cfg, timestep, text, emu):
     return temb, tproj, ctx
 
 
-def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu):
+def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False):
     p = f"blocks.{i}."
     d, H, eps = cfg.dim, cfg.num_attention_heads, cfg.eps
     mod = sd[p + "scale_shift_table"].float() + tproj.float()  # [B,6,d]
@@ -140,7 +140,12 @@ def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu):
     B, N, _ = q.shape
     q = apply_rope(q.view(B, N, H, -1).transpose(1, 2), freqs).transpose(1, 2).reshape(B, N, d)
     k = apply_rope(k.view(B, N, H, -1).transpose(1, 2), freqs).transpose(1, 2).reshape(B, N, d)
-    a = _lin(attention(q, k, v, H, emu), sd, p + "attn1.to_out.0", emu)
+    if fp8_attn:   # MI355X fp8 self-attention mode (see attention_fp8_emulated below): bf16 q, k, v -> e4m3, unit scales
+        hs = lambda t: _r(t, True).view(B, N, H, -1).transpose(1, 2)
+        ao = attention_fp8_emulated(hs(q), hs(k), hs(v), (d // H) ** -0.5).transpose(1, 2).reshape(B, N, d)
+        a = _lin(_r(ao, emu), sd, p + "attn1.to_out.0", emu)
+    else:
+        a = _lin(attention(q, k, v, H, emu), sd, p + "attn1.to_out.0", emu)
     x = _r(x.float() + a * gate_msa, emu)
     # 2. cross attention (norm2 has affine, no modulation; no mask over zero-padded text rows)
     n = _r(F.layer_norm(x.float(), (d,), sd[p + "norm2.weight"].float(), sd[p + "norm2.bias"].float(), eps), emu)
@@ -174,7 +179,7 @@ def unpatchify(cfg, tokens, Fr, Hh, Ww):
 
 
 def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.Tensor, timestep: torch.Tensor,
-                text: torch.Tensor, emulate_bf16: bool = False, num_layers: int | None = None) -> torch.Tensor:
+                text: torch.Tensor, emulate_bf16: bool = False, num_layers: int | None = None, fp8_attn: bool = False) -> torch.Tensor:
     """transformer(hidden_states[B,16,T,H,W], timestep[B], encoder_hidden_states[B,L,4096]) -> [B,16,T,H,W]."""
     emu = emulate_bf16
     B, C, Fr, Hh, Ww = latents.shape
@@ -186,7 +191,7 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.T
     temb, tproj, ctx = condition_embed(sd, cfg, timestep, text, emu)
     L = cfg.num_layers if num_layers is None else num_layers
     for i in range(L):
-        x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu)
+        x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn)
     shift, scale = (sd["scale_shift_table"].float() + temb.float().unsqueeze(1)).chunk(2, dim=1)
     x = _r(F.layer_norm(x.float(), (cfg.dim,), eps=cfg.eps) * (1 + scale) + shift, emu)
     x = _lin(x, sd, "proj_out", emu)
@@ -226,3 +231,32 @@ def make_weights(cfg: WanDiTConfig, seed: int = 0, dtype=torch.float32) -> Dict[
     sd["scale_shift_table"] = (torch.randn(1, 2, d, generator=g) / math.sqrt(d)).to(dtype)
     lin("proj_out", cfg.out_channels * pt * ph * pw, d)
     return sd
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# e4m3 emulation of the MI355X fp8 attention mode (vist3a_amd/csrc/attention_fp8.hip).  NOT part of the reference (which
+# computes this attention in bf16): it pins the arithmetic of the opt-in fp8 path of BASELINE config #4 - the rounding points
+# (q, k, v -> e4m3 per tensor scale; P -> e4m3 after a 2^8 pre-scale, per 64-key tile against the RUNNING maximum; l from the
+# unrounded p) - so that the kernel can be checked to fp32 round-off instead of against a loose fp8-vs-bf16 tolerance.
+def _e4m3(x: torch.Tensor) -> torch.Tensor:
+    return x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+
+
+def attention_fp8_emulated(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, q_scale: float = 1.0, k_scale: float = 1.0,
+                           v_scale: float = 1.0, tile: int = 64) -> torch.Tensor:
+    """q [.., Nq, D], k/v [.., Nk, D] (fp32 holding the bf16 values) -> [.., Nq, D] fp32."""
+    q8, k8, v8 = _e4m3(q.float() / q_scale), _e4m3(k.float() / k_scale), _e4m3(v.float() / v_scale)
+    c = scale * q_scale * k_scale
+    Nk = k.shape[-2]
+    m = torch.full(q.shape[:-1], -1e30)
+    l = torch.zeros(q.shape[:-1])
+    o = torch.zeros(q.shape)
+    for k0 in range(0, Nk, tile):
+        s = q8 @ k8[..., k0:k0 + tile, :].transpose(-1, -2)
+        m_new = torch.maximum(m, s.amax(-1))
+        alpha = torch.exp2((m - m_new) * (c * 1.4426950408889634))
+        p256 = torch.exp2((s - m_new[..., None]) * (c * 1.4426950408889634) + 8.0)
+        l = l * alpha + p256.sum(-1)
+        o = o * alpha[..., None] + (_e4m3(p256) / 256.0) @ v8[..., k0:k0 + tile, :]
+        m = m_new
+    return o * (256.0 * v_scale / l)[..., None]

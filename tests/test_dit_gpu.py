@@ -322,3 +322,26 @@ def test_full_depth_production_size_forward_matches_oracle(hip_lib, parity):
     print(f"full-depth 30-block N=4096 forward: rel {r:.3e} max abs {mx:.3e}")
     assert torch.isfinite(out).all()
     assert r < 3e-2, r
+
+
+def test_wan14b_width_fp8_attention_matches_e4m3_oracle(hip_lib, parity):
+    """BASELINE config #4 precision mode at Wan-14B width (40 heads x 128, FFN 13824, two blocks): self-attention on the fp8 MFMA
+    against the oracle with the same e4m3 rounding points emulated; same tolerance as the bf16 two-block forward.  Also reports how
+    far the fp8 mode moves the output from the bf16 mode (the price of the mode, not an error of the kernel)."""
+    from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
+    kw = dict(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=2, text_dim=256, freq_dim=256)
+    ocfg = O.WanDiTConfig(**kw)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=4).items()}
+    model = WanDiT(WanDiTConfig(**kw), sd, device="cuda")
+    g = torch.Generator().manual_seed(14)
+    lat = torch.randn(2, 16, 2, 16, 16, generator=g).to(torch.bfloat16)
+    text = (torch.randn(2, 48, 256, generator=g) * 0.5).to(torch.bfloat16).float()
+    t = torch.tensor([611, 611])
+    out16 = model(lat.cuda(), t.cuda(), text.cuda())[0].clone()
+    model.attn_dtype = "fp8"
+    out8 = model(lat.cuda(), t.cuda(), text.cuda())[0].clone()
+    ref8 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True)
+    r, shift = _rel(out8, ref8), _rel(out8, out16)
+    parity("dit_14B_width_fp8_attention", rel_vs_e4m3_oracle=r, rel_fp8_mode_vs_bf16_mode=shift)
+    print(f"14B-width fp8-attention forward: rel vs e4m3 oracle {r:.2e}; fp8 mode vs bf16 mode {shift:.2e}")
+    assert torch.isfinite(out8.float()).all() and r < 1.5e-2, r

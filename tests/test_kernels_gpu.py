@@ -420,3 +420,67 @@ def test_voxel_fusion_production_size_matches_scatter_reference(hip_lib, parity,
     assert ef < 1e-6 and ep < 1e-6, (ef, ep)
     again = ops.voxelize_fuse(pts, feat, C, C, 0.002)
     assert torch.equal(again["voxel_feat"], v["voxel_feat"]) and torch.equal(again["voxel_pts"], v["voxel_pts"])   # fixed summation order
+
+
+# ---------------------------------------------------------------- fp8 attention (BASELINE config #4) ----
+def _fp8_inputs(B, H, Nq, Nk, g, qk_std=1.0):
+    D = 128
+    q = (torch.randn(B, Nq, H * D, device=dev, generator=g) * qk_std).to(bf16)
+    k = (torch.randn(B, Nk, H * D, device=dev, generator=g) * qk_std).to(bf16)
+    v = torch.randn(B, Nk, H * D, device=dev, generator=g).to(bf16)
+    nkp = (Nk + 63) // 64 * 64
+    vt = torch.zeros(H * D, B * nkp, device=dev, dtype=bf16)
+    vt.view(H * D, B, nkp)[:, :, :Nk] = v.permute(2, 0, 1)
+    return q, k, v, vt, nkp
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 2, 256, 320), (2, 3, 200, 333), (1, 40, 512, 512)], ids=["small", "ragged", "14B_heads"])
+def test_attention_fp8_matches_e4m3_emulation(hip_lib, parity, B, H, Nq, Nk):
+    """The fp8 kernel against the oracle's e4m3 emulation with the SAME rounding points (per-tensor scales, P rounded per 64-key
+    tile against the running maximum): agreement to fp32 round-off + bf16 output rounding; and against exact fp32 attention to show
+    what the precision mode itself costs."""
+    from oracle import wan_dit as O
+    from vist3a_amd import ops
+    D = 128
+    g = torch.Generator(device=dev).manual_seed(31 + Nk)
+    q, k, v, vt, nkp = _fp8_inputs(B, H, Nq, Nk, g)
+    qs, ks, vs = 0.5, 0.25, 2.0
+    q8 = ops.quantize_fp8(q.view(B * Nq, H * D), qs)
+    k8 = ops.quantize_fp8(k.view(B * Nk, H * D), ks)
+    vt8 = ops.quantize_fp8(vt, vs)
+    ref8 = q.view(B * Nq, -1).float().div(qs).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(q8, ref8), "quantiser is not torch's RNE e4m3 rounding"
+    out = torch.empty(B * Nq, H * D, device=dev, dtype=bf16)
+    ops.attention_fp8(q8, k8, vt8, out, B=B, H=H, Nq=Nq, Nk=Nk, q_batch_stride=Nq * H * D, k_batch_stride=Nk * H * D,
+                      vt_batch_stride=nkp, o_batch_stride=Nq * H * D, q_scale=qs, k_scale=ks, v_scale=vs)
+    torch.cuda.synchronize()
+    out = out.view(B, Nq, H, D).float().cpu()
+    sh = lambda t, n: t.float().cpu().view(B, n, H, D).transpose(1, 2)
+    emu = O.attention_fp8_emulated(sh(q, Nq), sh(k, Nk), sh(v, Nk), D ** -0.5, qs, ks, vs).transpose(1, 2)
+    exact = torch.softmax(sh(q, Nq) @ sh(k, Nk).transpose(-1, -2) * D ** -0.5, -1) @ sh(v, Nk)
+    r_emu, r_exact = relerr(out, emu), relerr(out, exact.transpose(1, 2))
+    parity("attention_fp8", B=B, H=H, Nq=Nq, Nk=Nk, rel_vs_e4m3_emulation=r_emu, rel_vs_exact_fp32=r_exact)
+    print(f"fp8 attention: rel vs e4m3 emulation {r_emu:.2e}, vs exact fp32 {r_exact:.2e}")
+    assert r_emu < 3e-3, r_emu          # bf16 output rounding + exp2 ulp flips at e4m3 rounding boundaries of P
+    assert r_exact < 6e-2, r_exact      # what e4m3 operands cost (3 mantissa bits)
+
+
+def test_attention_fp8_production_shape_and_speed(hip_lib, parity):
+    """Wan-14B self-attention launch (B=1 per CFG branch, 40 heads, 4096 x 4096): finite, deterministic, close to bf16 attention."""
+    from vist3a_amd import ops
+    B, H, N, D = 1, 40, 4096, 128
+    g = torch.Generator(device=dev).manual_seed(77)
+    q, k, v, vt, nkp = _fp8_inputs(B, H, N, N, g)
+    q8, k8, vt8 = ops.quantize_fp8(q.view(N, H * D)), ops.quantize_fp8(k.view(N, H * D)), ops.quantize_fp8(vt)
+    outs = []
+    for _ in range(2):
+        o = torch.empty(N, H * D, device=dev, dtype=bf16)
+        ops.attention_fp8(q8, k8, vt8, o, B=B, H=H, Nq=N, Nk=N, q_batch_stride=N * H * D, k_batch_stride=N * H * D, vt_batch_stride=nkp,
+                          o_batch_stride=N * H * D)
+        outs.append(o)
+    ob = _run_attn(q, k, vt, nkp, B, H, N, N, D).view(N, H * D)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0].float()).all()
+    r = relerr(outs[0], ob)
+    parity("attention_fp8_vs_bf16_kernel_14B_shape", rel=r)
+    assert r < 6e-2, r

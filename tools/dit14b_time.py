@@ -14,12 +14,18 @@ text = torch.zeros(2, 512, 4096, device="cuda")
 text[0, :64] = torch.randn(64, 4096, device="cuda") * 0.1
 text[1, :80] = torch.randn(80, 4096, device="cuda") * 0.1
 t = torch.tensor([900, 900], device="cuda")
-a = m(lat, t, text)[0].clone()
-b = m(lat, t, text)[0].clone()
-torch.cuda.synchronize(); t0 = time.time()
-for _ in range(3): m(lat, t, text)
-torch.cuda.synchronize(); ms = (time.time() - t0) / 3 * 1e3
 N, d, ffn, L, ctx = 4096, cfg.dim, cfg.ffn_dim, cfg.num_layers, 512
 fl = 2 * L * (8 * N * d * d + 4 * N * N * d + 4 * N * d * d + 4 * N * ctx * d + 4 * N * d * ffn)
-print(json.dumps(dict(ms_per_cfg_pair=round(ms, 1), model_tflops=round(fl / ms / 1e9, 1), deterministic=bool(torch.equal(a, b)), finite=bool(torch.isfinite(a.float()).all()),
-                      peak_GB=round(torch.cuda.max_memory_allocated() / 2**30, 1))))
+outs = {}
+for mode in ("bf16", "fp8"):   # fp8 = self-attention on the block-scaled e4m3 MFMA (config #4), everything else bf16
+    m.attn_dtype = mode
+    a = m(lat, t, text)[0].clone()
+    b = m(lat, t, text)[0].clone()
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(3): m(lat, t, text)
+    torch.cuda.synchronize(); ms = (time.time() - t0) / 3 * 1e3
+    outs[mode] = a
+    print(json.dumps(dict(attention=mode, ms_per_cfg_pair=round(ms, 1), model_tflops=round(fl / ms / 1e9, 1), deterministic=bool(torch.equal(a, b)),
+                          finite=bool(torch.isfinite(a.float()).all()), peak_GB=round(torch.cuda.max_memory_allocated() / 2**30, 1))), flush=True)
+rel = ((outs["fp8"].float() - outs["bf16"].float()).norm() / outs["bf16"].float().norm()).item()
+print(json.dumps(dict(fp8_vs_bf16_forward_rel=rel)))

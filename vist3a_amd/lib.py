@@ -97,6 +97,17 @@ class AttnArgs(C.Structure):
     ]
 
 
+class AttnFp8Args(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p),
+        ("q_batch_stride", C.c_long), ("k_batch_stride", C.c_long),
+        ("vt_batch_stride", C.c_long), ("o_batch_stride", C.c_long),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int),
+        ("scale", C.c_float), ("q_scale", C.c_float), ("k_scale", C.c_float), ("v_scale", C.c_float),
+    ]
+
+
 class LayerNormArgs(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("y", C.c_void_p),
@@ -140,6 +151,8 @@ SYMBOLS = {
     "v3a_gemm_tile_name": (C.c_char_p, [C.c_int]),
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    "v3a_attention_fwd_fp8": (C.c_int, [C.POINTER(AttnFp8Args), C.c_void_p]),
+    "v3a_quantize_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "v3a_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "v3a_rmsnorm_rope": (C.c_int, [C.POINTER(RmsNormRopeArgs), C.c_void_p]),
     "v3a_rownorm_act": (C.c_int, [C.POINTER(RowNormArgs), C.c_void_p]),

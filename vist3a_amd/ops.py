@@ -294,6 +294,32 @@ def attention(
     return out
 
 
+def quantize_fp8(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 [rows, cols] (row stride = x.stride(0)) -> e4m3 bytes (uint8 storage) of x / scale, RNE, clamped to +-448."""
+    _chk2d(x, "x", (bf16,))
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(rows, cols, device=x.device, dtype=torch.uint8)
+    if out.dtype != torch.uint8 or out.dim() != 2 or out.stride(1) != 1 or tuple(out.shape) != (rows, cols):
+        raise ValueError("out must be a uint8 [rows, cols] tensor with a contiguous last dim")
+    L.check(L.load().v3a_quantize_fp8(_ptr(x), _ptr(out), rows, cols, x.stride(0), out.stride(0), float(scale), _stream()), "v3a_quantize_fp8")
+    return out
+
+
+def attention_fp8(q8: torch.Tensor, k8: torch.Tensor, vt8: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Nq: int, Nk: int,
+                  q_batch_stride: int, k_batch_stride: int, vt_batch_stride: int, o_batch_stride: int, scale: Optional[float] = None,
+                  q_scale: float = 1.0, k_scale: float = 1.0, v_scale: float = 1.0) -> torch.Tensor:
+    """fp8 (e4m3) flash attention, head dim 128: q8/k8 uint8 [B*N, >=H*128], vt8 uint8 [H*128, >=B*vt_batch_stride], out bf16."""
+    for t, n in ((q8, "q8"), (k8, "k8"), (vt8, "vt8")):
+        _chk2d(t, n, (torch.uint8,))
+    _chk2d(out, "out", (bf16,))
+    args = L.AttnFp8Args(_ptr(q8), _ptr(k8), _ptr(vt8), _ptr(out), q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride,
+                         q8.stride(0), k8.stride(0), vt8.stride(0), out.stride(0), B, H, Nq, Nk, 128,
+                         float(scale if scale is not None else 128 ** -0.5), float(q_scale), float(k_scale), float(v_scale))
+    L.check(L.load().v3a_attention_fwd_fp8(C.byref(args), _stream()), "v3a_attention_fwd_fp8")
+    return out
+
+
 def layernorm(
     x: torch.Tensor, *, out: Optional[torch.Tensor] = None,
     weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,

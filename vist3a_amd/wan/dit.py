@@ -106,6 +106,7 @@ class _Workspace:
         if P == 1:
             self.qk = e(M, 2 * d)
             self.vt = torch.zeros(d, B * ((N + 63) // 64 * 64), device=device, dtype=bf16)
+            self.qk8 = self.vt8 = None   # e4m3 copies, allocated on first use of the fp8 attention mode
         else:  # sequence-parallel: local q, packed local [K | V^T] to send, gathered slabs, full K / V^T
             self.q = e(M, d)
             self.pack = e(2 * M * d)
@@ -127,6 +128,10 @@ class WanDiT:
         self._rope: Dict[tuple, torch.Tensor] = {}
         self._ctx: Dict[tuple, tuple] = {}  # (B, L, thread) -> (prompt key, persistent cross-attention K / V^T buffers)
         self.merge_padding_keys = True      # see _context
+        # "fp8": self-attention on the block-scaled fp8 MFMA (BASELINE config #4; csrc/attention_fp8.hip): q / k (after RMSNorm + RoPE)
+        # and V^T are rounded to e4m3 with the unit scales below.  "bf16" (default) is the reference's precision.
+        self.attn_dtype = "bf16"
+        self.fp8_scales = (1.0, 1.0, 1.0)
         self._load(state_dict)
 
     # ---------------------------------------------------------------- weights
@@ -282,8 +287,19 @@ class WanDiT:
                         ops.gemm(b["wv"], ws.n[bi * N:(bi + 1) * N], b["bv"], out=ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True)
                 ops.rmsnorm_rope(q, b["nq"], out=q, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps)
                 ops.rmsnorm_rope(k, b["nk"], out=k, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps)
-                ops.attention(q, k, ws.vt, ws.ao, B=B, H=H, Nq=N, Nk=N, D=hd, q_batch_stride=N * 2 * d,
-                              k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d)
+                if self.attn_dtype == "fp8":
+                    if ws.qk8 is None:
+                        ws.qk8 = torch.empty(ws.qk.shape, device=ws.qk.device, dtype=torch.uint8)
+                        ws.vt8 = torch.zeros(ws.vt.shape, device=ws.vt.device, dtype=torch.uint8)
+                    qs, ksc, vs = self.fp8_scales
+                    ops.quantize_fp8(q, qs, out=ws.qk8[:, :d])
+                    ops.quantize_fp8(k, ksc, out=ws.qk8[:, d:])
+                    ops.quantize_fp8(ws.vt, vs, out=ws.vt8)
+                    ops.attention_fp8(ws.qk8[:, :d], ws.qk8[:, d:], ws.vt8, ws.ao, B=B, H=H, Nq=N, Nk=N, q_batch_stride=N * 2 * d,
+                                      k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d, q_scale=qs, k_scale=ksc, v_scale=vs)
+                else:
+                    ops.attention(q, k, ws.vt, ws.ao, B=B, H=H, Nq=N, Nk=N, D=hd, q_batch_stride=N * 2 * d,
+                                  k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d)
             else:
                 # K and V^T of the local tokens first, so their all-gather rides under the Q projection
                 ops.gemm(ws.n, b["wqk"][d:], b["bqk"][d:], out=kl)
