@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 8) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 9) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -126,6 +126,11 @@ typedef struct {
                              * Used to merge the identical zero-padding keys of a prompt into one key carrying log(count). */
   int key_bias_stride;
   int key_bias_first;       /* keys < key_bias_first have zero bias (their tiles skip the bias loads); 0 = any key may carry bias */
+  int kv_seg;               /* optional (D = 128 only): keys of a batch item are split into segments of kv_seg keys (multiple of 64, divides Nk),
+                             * segment s of K at k + s * k_seg_stride, of V^T at vt + s * vt_seg_stride (elements): the all-gathered per-rank
+                             * slabs of sequence-parallel attention are read in place.  Inside a segment: ldk / k_batch_stride / ldvt /
+                             * vt_batch_stride as usual */
+  long k_seg_stride, vt_seg_stride;
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 

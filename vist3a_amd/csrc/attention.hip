@@ -44,6 +44,8 @@ struct AttnP {
   float inv_scale;                // bias is added to the raw score as bias / softmax_scale
   const float* kbias;             // KBIAS: additive per-key bias [B][kbias_stride] (log-multiplicity of merged identical keys)
   int kbias_stride, kbias_first;  // keys below kbias_first have zero bias: tiles entirely below it skip the loads
+  int kv_seg;                     // > 0: keys live in segments of kv_seg (a multiple of 64) keys, one per all-gathered rank slab:
+  long k_seg, vt_seg;             //      key kk of a batch item is row (kk % kv_seg) of segment kk / kv_seg, segments k_seg / vt_seg elements apart
 };
 
 template <int D, int NW, bool RELB>
@@ -353,18 +355,22 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     vp[j] = Vb + ((size_t)r * p.ldvt + c * 8) * 2;
   }
+  // with kv_seg (sequence-parallel: K / V^T are read straight from the all-gathered per-rank slabs, no reassembly copy) a 64-key
+  // tile lies inside one segment: its wave-uniform base moves by (k_seg - kv_seg * ldk) / (vt_seg - kv_seg) per segment crossed
   auto stage_k = [&](int s, int kt) {
     char* sb = smem + s * KTILE;
+    const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.k_seg - (long)p.kv_seg * p.ldk) * 2 : 0;
 #pragma unroll
     for (int j = 0; j < KINS; ++j) {
       int row = kt * KV + krow[j];
       row = row < p.Nk ? row : p.Nk - 1;
-      glds16(kp[j] + (size_t)row * p.ldk * 2, sb + (j * NW + wave) * 1024);
+      glds16(kp[j] + (size_t)row * p.ldk * 2 + so, sb + (j * NW + wave) * 1024);
     }
   };
   auto stage_v = [&](int kt) {
+    const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.vt_seg - p.kv_seg) * 2 : 0;
 #pragma unroll
-    for (int j = 0; j < VINS; ++j) glds16(vp[j] + (size_t)kt * KV * 2, smem + 2 * KTILE + (j * NW + wave) * 1024);
+    for (int j = 0; j < VINS; ++j) glds16(vp[j] + (size_t)kt * KV * 2 + so, smem + 2 * KTILE + (j * NW + wave) * 1024);
   };
 
   // ---- fragment read offsets ----
@@ -593,7 +599,8 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   if (a->q_batch_stride % 8 || a->k_batch_stride % 8 || a->vt_batch_stride % 8 || a->o_batch_stride % 8)
     return V3A_ERR_SHAPE;
   // V^T rows must be readable (and finite, ideally zero) up to the next multiple of 64 keys
-  if (a->vt_batch_stride && a->vt_batch_stride < a->Nk && a->B > 1) return V3A_ERR_SHAPE;
+  if (!a->kv_seg && a->vt_batch_stride && a->vt_batch_stride < a->Nk && a->B > 1) return V3A_ERR_SHAPE;
+  if (a->kv_seg > 0 && a->vt_batch_stride && a->vt_batch_stride < a->kv_seg && a->B > 1) return V3A_ERR_SHAPE;
   if (a->kv_period < 0 || (a->kv_period > 0 && (a->kv_valid <= 0 || a->kv_valid > a->kv_period))) return V3A_ERR_ARG;
   AttnP p;
   p.q = (const char*)a->q; p.k = (const char*)a->k; p.vt = (const char*)a->vt; p.o = (char*)a->o;
@@ -610,10 +617,13 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   }
   static const bool two_per_cu = getenv("V3A_ATTN_OCC2") != nullptr;  // A/B switch for the older 2-workgroup schedule
   p.kbias = a->key_bias; p.kbias_stride = a->key_bias_stride; p.kbias_first = a->key_bias_first > 0 ? a->key_bias_first : 0;
+  p.kv_seg = a->kv_seg; p.k_seg = a->k_seg_stride; p.vt_seg = a->vt_seg_stride;
+  if (a->kv_seg < 0 || (a->kv_seg > 0 && (a->kv_seg % 64 || a->Nk % a->kv_seg || a->D != 128 || a->rel_bias || a->key_bias ||
+                                         a->k_seg_stride % 8 || a->vt_seg_stride % 8))) return V3A_ERR_SHAPE;
   if (a->key_bias) {
     if (a->D != 128 || a->rel_bias || a->key_bias_stride < a->Nk) return V3A_ERR_SHAPE;
     return launch_attn3<128, 4, true>(p, a->B, stream);
   }
-  if (a->D == 128) return two_per_cu ? launch_attn<128, 4, false>(p, a->B, stream) : launch_attn3<128, 4, false>(p, a->B, stream);
+  if (a->D == 128) return (two_per_cu && !a->kv_seg) ? launch_attn<128, 4, false>(p, a->B, stream) : launch_attn3<128, 4, false>(p, a->B, stream);
   return launch_attn<64, 4, false>(p, a->B, stream);  // recon (hd = 64): the 3-per-CU schedule measured no gain there
 }

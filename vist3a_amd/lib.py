@@ -94,6 +94,7 @@ class AttnArgs(C.Structure):
         ("scale", C.c_float), ("kv_period", C.c_int), ("kv_valid", C.c_int),
         ("rel_bias", C.c_void_p), ("rel_bias_stride", C.c_int), ("rel_bias_center", C.c_int),
         ("key_bias", C.c_void_p), ("key_bias_stride", C.c_int), ("key_bias_first", C.c_int),
+        ("kv_seg", C.c_int), ("k_seg_stride", C.c_long), ("vt_seg_stride", C.c_long),
     ]
 
 

@@ -309,10 +309,16 @@ class WanDiT:
                 ops.gemm(ws.n, b["wqk"][:d], b["bqk"][:d], out=ws.q)
                 ops.rmsnorm_rope(ws.q, b["nq"], out=ws.q, rope=rope, head_dim=hd, tokens_per_batch=Nl, eps=cfg.eps)
                 pending.wait()
-                ws.kfull.view(B, P, Nl, d).copy_(ws.gbuf[:, :Ml * d].view(P, B, Nl, d).permute(1, 0, 2, 3))
-                vt_full.view(d, B, P, Nl).copy_(ws.gbuf[:, Ml * d:].view(P, d, B, Nl).permute(1, 2, 0, 3))
-                ops.attention(ws.q, ws.kfull, ws.vt, ws.ao, B=B, H=H, Nq=Nl, Nk=N, D=hd, q_batch_stride=Nl * d,
-                              k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=Nl * d)
+                if Nl % 64 == 0:
+                    # the flash kernel walks the gathered slabs in place: rank r's [K | V^T] pack is segment r (keys r*Nl .. (r+1)*Nl)
+                    ops.attention(ws.q, ws.gbuf[0, :Ml * d].view(Ml, d), ws.gbuf[0, Ml * d:].view(d, Ml), ws.ao, B=B, H=H, Nq=Nl, Nk=N,
+                                  D=hd, q_batch_stride=Nl * d, k_batch_stride=Nl * d, vt_batch_stride=Nl, o_batch_stride=Nl * d,
+                                  kv_seg=Nl, k_seg_stride=2 * Ml * d, vt_seg_stride=2 * Ml * d)
+                else:  # ragged shard: reassemble K [B*N, d] and V^T [d, B*N] (two copies per block)
+                    ws.kfull.view(B, P, Nl, d).copy_(ws.gbuf[:, :Ml * d].view(P, B, Nl, d).permute(1, 0, 2, 3))
+                    vt_full.view(d, B, P, Nl).copy_(ws.gbuf[:, Ml * d:].view(P, d, B, Nl).permute(1, 2, 0, 3))
+                    ops.attention(ws.q, ws.kfull, ws.vt, ws.ao, B=B, H=H, Nq=Nl, Nk=N, D=hd, q_batch_stride=Nl * d,
+                                  k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=Nl * d)
             ops.gemm(ws.ao, b["wo"], b["bo"], out=x, residual=x, scale=m[:, 2], rows_per_batch=Nl)
             # --- cross attention
             ops.layernorm(x, out=ws.n, weight=b["n2w"], bias=b["n2b"], eps=cfg.eps)
