@@ -35,7 +35,7 @@ def pmc_traffic(kernel_key: str):
         try:
             k = json.loads(f.read_text())["kernels"]
             for name, v in k.items():
-                if name.replace(" ", "").startswith(kernel_key):
+                if name.replace(" ", "").startswith(kernel_key.replace(" ", "")):
                     best = v["hbm_bytes_per_launch"]
         except Exception:  # noqa: BLE001
             pass
@@ -257,9 +257,9 @@ def main():
                                                           / (stage.denoise_ms * 1e-3) / 1e12, 1),
                        "dit_flops_note": f"model = BASELINE.md §2 formula (512 text keys, context K/V projected every step); executed = "
                                          f"{ctx_keys} cross-attention keys after merging the zero-padding keys, context K/V cached per prompt"},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel<{lib.load().v3a_gemm_tile_name(dom_tile).decode()}> (bf16 MFMA 32x32x16)",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_pp_kernel<3, true, 5, 0> = tile {lib.load().v3a_gemm_tile_name(dom_tile).decode()} (bf16 MFMA 32x32x16, ping-pong 256x192)",
                          "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic("gemm_nt_kernel<256,192,4,2,64,2,false,0"), "traffic_unit": "bytes/launch (PMC, profiles/)",
+                         "traffic": pmc_traffic("gemm_pp_kernel<3,true"), "traffic_unit": "bytes/launch (PMC, profiles/)",
                          "launches_timed": ps["launches"], "avg_launch_ms": round(ps["avg_ms"], 4),
                          "flops_per_launch": ps["flops_per_launch"]},
         }

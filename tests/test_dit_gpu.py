@@ -321,7 +321,7 @@ def test_full_depth_production_size_forward_matches_oracle(hip_lib, parity):
     parity("dit_full_depth_30_blocks_N4096", rel_vs_emu_oracle=r, max_abs=mx, ref_rms=ref.pow(2).mean().sqrt().item())
     print(f"full-depth 30-block N=4096 forward: rel {r:.3e} max abs {mx:.3e}")
     assert torch.isfinite(out).all()
-    assert r < 3e-2, r
+    assert r < 2e-2, r   # measured 8.8e-3 on MI355X (profiles/r2/parity.json): 30 blocks of bf16 rounding and bf16-P flash attention
 
 
 def test_wan14b_width_fp8_attention_matches_e4m3_oracle(hip_lib, parity):

@@ -86,7 +86,7 @@ def test_gemm_production_shapes_every_tile(hip_lib, parity, name, M, N, K, opt):
         r = relerr(out, ref)
         worst = max(worst, r)
         parity("gemm_production", shape=name, M=M, N=N, K=K, tile=tn, auto=(t == auto), rel_vs_fp32=r)
-        assert math.isfinite(r) and r < 2e-4, (tn, r)
+        assert math.isfinite(r) and r < 1.2e-4, (tn, r)   # measured <= 5.5e-5 (profiles/r2/parity.json)
         if first is None:
             first = out
         else:
@@ -132,7 +132,7 @@ def test_gemm_epilogue_flags_every_tile(hip_lib, parity):
             r = relerr(out, ref)
             parity("gemm_flags", case={k: v for k, v in c.items()}, tile=tn, rel_vs_fp32=r)
             # erf/tanh GELU: device transcendental vs torch's differ by an ulp before the bf16 rounding (measured <= 6e-4)
-            assert math.isfinite(r) and r < (1.5e-3 if kw["act"] in (L.ACT_GELU_ERF, L.ACT_GELU_TANH, L.ACT_SILU) else 2e-4), (tn, c, r)
+            assert math.isfinite(r) and r < (1.5e-3 if kw["act"] in (L.ACT_GELU_ERF, L.ACT_GELU_TANH, L.ACT_SILU) else 1.2e-4), (tn, c, r)
             if first is None:
                 first = out
             else:
@@ -291,7 +291,7 @@ def test_conv_variants_match_torch_conv3d(hip_lib, parity, case):
     r = relerr(y[..., :Cout], refcl)
     parity("conv_variant", name=name, rel_vs_fp32=r)
     assert tuple(y.shape[:3]) == tuple(ref.shape[2:])
-    assert r < 3e-4, (name, r)
+    assert r < 1.5e-4, (name, r)   # measured <= 6.2e-5
     if cw.CoutP != Cout:
         assert (y[..., Cout:].float() - res[..., Cout:].float()).abs().max() == 0
 
@@ -371,7 +371,7 @@ def test_norm_kernels_production_shapes(hip_lib, parity):
         idx = torch.arange(M, device=dev) // (rpb or M)
         r = relerr(y, (ln * (1 + sc[idx]) + sh[idx]).to(bf16))
         parity("layernorm_adaln", M=M, d=d, rel_vs_fp32=r)
-        assert r < 2e-4, r
+        assert r < 4e-5, r   # measured 1.5e-5 (bf16 output rounding flips)
         xf = x.float() * 1.37
         y = ops.layernorm(xf, weight=w, bias=b, eps=1e-5, out_dtype=f32)
         r = relerr(y, torch.nn.functional.layer_norm(xf, (d,), w, b, eps=1e-5))
@@ -390,7 +390,7 @@ def test_norm_kernels_production_shapes(hip_lib, parity):
         fc = torch.polar(torch.ones_like(ang), ang)[None, :, None, :]
         r = relerr(y, torch.view_as_real(nc * fc).reshape(M, d).to(bf16))
         parity("rmsnorm_rope", B=B, N=N, rel_vs_fp32=r)
-        assert r < 2e-4, r
+        assert r < 6e-5, r   # measured 2.2e-5
 
 
 @pytest.mark.parametrize("spread", [0.03, 0.25], ids=["7_points_per_voxel", "1_point_per_voxel"])

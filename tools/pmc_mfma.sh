@@ -17,8 +17,9 @@ for f in glob.glob("$R/gpurun_out/pmc_mfma/*counter_collection.csv"):
 out = {}
 for k, d in acc.items():
     if "GRBM_GUI_ACTIVE" not in d or d["GRBM_GUI_ACTIVE"] == 0: continue
-    util = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["GRBM_GUI_ACTIVE"] * 256 * 4)
+    util = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["GRBM_GUI_ACTIVE"] / 8 * 256 * 4)  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
     out[k[:110]] = dict(dispatches=n[(k, "GRBM_GUI_ACTIVE")], gui_active_cycles_total=d["GRBM_GUI_ACTIVE"], mfma_busy_cycles_total=d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), mfma_util=round(util, 4))
 top = dict(sorted(out.items(), key=lambda kv: -kv[1]["gui_active_cycles_total"])[:12])
+open("$R/gpurun_out/pmc_mfma.json", "w").write(json.dumps(top, indent=1))
 print(json.dumps(top, indent=1))
 PY
