@@ -114,6 +114,7 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
   static_assert(PFB > 0 && ITERS % PB == 0, "prefetch batch");
   const int flags = p.flags;
   const bool res_f32 = (flags & V3A_GEMM_RES_F32) != 0;
+  const bool plain = !p.scale && !p.res && !p.res2 && !(flags & (V3A_GEMM_RELU_OUT | V3A_GEMM_OUT_F32)) && p.orow_group <= 0;
 
   // prefetched operands of one row chunk (8 consecutive columns of one output row)
   u32x4 pr0[PB], pr1[PB];   // residual: bf16 x8 in pr0, or f32 x8 in pr0|pr1
@@ -152,9 +153,22 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
     for (int j = 0; j < NTL; ++j) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][j][g * 4 + e];
+          if constexpr (ACT != V3A_ACT_NONE) {   // act(bf16(acc + bias)), applied here on the registers: phase 2 then only copies
+            float x = round_bf16(v[e]);
+            if constexpr (ACT == V3A_ACT_GELU_TANH) x = gelu_tanh(x);
+            else if constexpr (ACT == V3A_ACT_GELU_ERF) x = gelu_erf(x);
+            else if constexpr (ACT == V3A_ACT_SILU) x = silu(x);
+            else x = fmaxf(x, 0.f);
+            v[e] = x;
+          }
+        }
         u32x2 pk;
-        pk[0] = pack_bf16x2(acc[i][j][g * 4], acc[i][j][g * 4 + 1]);
-        pk[1] = pack_bf16x2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        pk[0] = pack_bf16x2(v[0], v[1]);
+        pk[1] = pack_bf16x2(v[2], v[3]);
         *(u32x2*)(reg + l31 * PITCH + (j * 32 + g * 8 + hi * 4) * 2) = pk;
       }
     }
@@ -176,19 +190,14 @@ __device__ __forceinline__ void gemm_epilogue_act(const GemmP& p, f32x16 (&acc)[
         const bool inside = m < p.M && n < p.N;
         u32x4 raw;
         raw[0] = lo[0]; raw[1] = lo[1]; raw[2] = hi2[0]; raw[3] = hi2[1];
+        if (plain) {   // nothing left to fuse: the parked bf16 row chunk IS the output
+          if constexpr (!(DBG & 1)) {
+            if (inside) *(u32x4*)(p.C + ((size_t)m * p.ldc + n) * 2) = raw;
+          }
+          continue;
+        }
         float v[8];
         unpack_bf16x8(raw, v);
-        if constexpr (ACT != V3A_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = v[e];
-            if constexpr (ACT == V3A_ACT_GELU_TANH) x = gelu_tanh(x);
-            else if constexpr (ACT == V3A_ACT_GELU_ERF) x = gelu_erf(x);
-            else if constexpr (ACT == V3A_ACT_SILU) x = silu(x);
-            else x = fmaxf(x, 0.f);
-            v[e] = round_bf16(x);
-          }
-        }
         if (p.scale) {
           if (aux.lds_scale) {
             const char* sp = aux.lds_scale + (min(n, p.N - 8) - aux.n0) * 4;
