@@ -24,6 +24,7 @@ if str(ROOT) not in sys.path:
 import torch
 
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+FP8_MFMA_PEAK_TFLOPS = 5000.0   # dense fp8 (--dtype fp8 only)
 
 
 def pmc_traffic(kernel_key: str):
@@ -108,6 +109,10 @@ def dit_flops_executed(N, d, ffn, L, ctx_keys: int):
     return L * (8 * N * d * d + 4 * N * N * d + 4 * N * d * d + 4 * N * ctx_keys * d + 4 * N * d * ffn)
 
 
+def coop_requested(a, world):
+    return a.parallel == "scene" and world > 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,8 +125,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", choices=["1.3b", "14b"], default="1.3b",
                     help="14b = BASELINE config #4 geometry (Wan-14B, 40 x 128 heads, FFN 13824, 40 blocks); NOT the headline config")
-    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
-                    help="fp8: DiT self-attention on the block-scaled e4m3 MFMA (config #4's precision mode); GEMMs stay bf16")
+    ap.add_argument("--dtype", choices=["bf16", "fp8", "fp8-attn"], default="bf16",
+                    help="fp8: config #4's precision mode - DiT self-attention AND the block projection / FFN GEMMs on the e4m3 MFMA "
+                         "(per-token / per-channel scales); fp8-attn: the attention only, GEMMs stay bf16")
     ap.add_argument("--parallel", choices=["dp", "scene"], default="dp",
                     help="dp: one prompt per GPU, no data-path collective (the reference's split; the headline metric). "
                          "scene: all ranks cooperate on ONE scene (CFG-parallel x sequence-parallel DiT over RCCL; latency mode)")
@@ -146,7 +152,11 @@ def main():
     lib.load()
     cfg = WAN_14B if a.model == "14b" else WAN_1_3B
     model = Text23DGS.synthetic(cfg, seed=0, device=dev)
-    model.transformer.attn_dtype = a.dtype
+    model.transformer.attn_dtype = "bf16" if a.dtype == "bf16" else "fp8"
+    if a.dtype == "fp8":
+        if coop_requested(a, world):
+            raise SystemExit("--dtype fp8 (e4m3 GEMMs) covers the single-GPU DiT path; use --dtype fp8-attn with --parallel scene")
+        model.transformer.enable_fp8_gemm()
     pe, ne = synthetic_text_embeddings(dev)
     coop = a.parallel == "scene" and world > 1
     if coop:
@@ -172,8 +182,9 @@ def main():
     for i in range(a.warmup):
         scene(-1 - i)
     # dominant kernel = the bf16 GEMM tile every N=1536/3072/8960-wide projection resolves to (one kernel symbol)
-    dom_tile = lib.load().v3a_gemm_pick_tile(2 * N, cfg.dim)
-    probe = ops.GemmProbe(dom_tile)
+    f8 = a.dtype == "fp8"   # then the dominant kernel is the e4m3 form of the same tile
+    dom_tile = lib.load().v3a_gemm_fp8_pick_tile(2 * N, cfg.dim) if f8 else lib.load().v3a_gemm_pick_tile(2 * N, cfg.dim)
+    probe = ops.GemmProbe(dom_tile, fp8=f8)
     ops.set_gemm_probe(probe)
     stage = SceneTimes()
     sync()
@@ -242,7 +253,8 @@ def main():
             "metric": "3D Gaussian scenes/sec (50-step denoise, 512^2, 13 views)",
             "value": (1 if coop else world) * a.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if coop else "weak", "vs_baseline": None,
-            "dtype": a.dtype if a.dtype == "bf16" else "fp8 (e4m3 self-attention operands; bf16 GEMMs)",
+            "dtype": {"bf16": "bf16", "fp8-attn": "fp8 (e4m3 self-attention operands; bf16 GEMMs)",
+                      "fp8": "fp8 (e4m3 self-attention and block projection / FFN GEMM operands, fp32 accumulation; bf16 elsewhere)"}[a.dtype],
             "data": "synthetic (seeded random weights of production shapes, synthetic text embeddings)",
             "config": {"workload": f"Wan-{'14B' if a.model == '14b' else '1.3B'} stitched, {a.denoise_steps}-step CFG denoise (batch-2 cond/uncond), {a.num_frames} views @512, "
                                    "VAE decode, 448^2 AnySplat enc_blocks_2 reconstruction with voxel fusion; "
@@ -257,9 +269,12 @@ def main():
                                                           / (stage.denoise_ms * 1e-3) / 1e12, 1),
                        "dit_flops_note": f"model = BASELINE.md §2 formula (512 text keys, context K/V projected every step); executed = "
                                          f"{ctx_keys} cross-attention keys after merging the zero-padding keys, context K/V cached per prompt"},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_pp_kernel<3, true, 5, 0> = tile {lib.load().v3a_gemm_tile_name(dom_tile).decode()} (bf16 MFMA 32x32x16, ping-pong 256x192)",
-                         "achieved": round(ach, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": pmc_traffic("gemm_pp_kernel<3,true"), "traffic_unit": "bytes/launch (PMC, profiles/)",
+            "roofline": {"bound": "mfma",
+                         "kernel": (f"gemm_pp_kernel<.., F8> = tile {lib.load().v3a_gemm_fp8_tile_name(dom_tile).decode()} (e4m3 MFMA 32x32x64 f8f6f4, ping-pong)" if f8 else
+                                    f"gemm_pp_kernel<3, true, 5, 0> = tile {lib.load().v3a_gemm_tile_name(dom_tile).decode()} (bf16 MFMA 32x32x16, ping-pong 256x192)"),
+                         "achieved": round(ach, 1), "peak": FP8_MFMA_PEAK_TFLOPS if f8 else BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / (FP8_MFMA_PEAK_TFLOPS if f8 else BF16_MFMA_PEAK_TFLOPS), 4),
+                         "traffic": None if f8 else pmc_traffic("gemm_pp_kernel<3,true"), "traffic_unit": "bytes/launch (PMC, profiles/)",
                          "launches_timed": ps["launches"], "avg_launch_ms": round(ps["avg_ms"], 4),
                          "flops_per_launch": ps["flops_per_launch"]},
         }

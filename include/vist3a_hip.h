@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 9) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 10) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -74,6 +74,26 @@ int v3a_gemm_bf16_nt(const v3a_gemm_args* args, void* stream);
 int v3a_gemm_num_tiles(void);
 int v3a_gemm_pick_tile(int M, int N);   /* the tile index tile=-1 resolves to (profiling / roofline bookkeeping) */
 const char* v3a_gemm_tile_name(int tile);
+
+/* e4m3 (OCP fp8) form of v3a_gemm_bf16_nt for BASELINE config #4 (Wan-14B: "MFMA bf16/fp8 GEMMs for the attention/FFN contractions"):
+ *   C[m][n] = epilogue( a_scale[m] * b_scale[n] * sum_k A8[m][k] * B8[n][k] )        (fp32 accumulation, scales multiplied first)
+ * A8 [M][lda], B8 [N][ldb] are e4m3 BYTES (K % 128 == 0, lda/ldb % 16 == 0) as written by v3a_quantize_fp8_rows (per-row dynamic
+ * scales: activations per token, weights per output channel).  Everything after the dequantisation - bias, activation, gate scale,
+ * residuals, output type, row scatter, flags - is the bf16 GEMM's epilogue, field for field (g.*).  The main loop is the ping-pong
+ * loop of v3a_gemm_bf16_nt with v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales) in place of the bf16 MFMA: same bytes per
+ * LDS row, twice the K per phase.  g.tile: -1 = heuristic, or 0 .. v3a_gemm_fp8_num_tiles()-1.
+ * v3a_quantize_fp8_rows: scale[r] = max(amax_r, 1e-12) / 448 (IEEE), y[r][c] = e4m3(clamp(x[r][c] * (1 / scale[r]), +-448)), RNE.
+ * x bf16 [rows][ldx] (cols % 8 == 0), y bytes [rows][ldy], scale fp32 [rows]. */
+typedef struct {
+  v3a_gemm_args g;          /* A, B: e4m3 bytes; lda, ldb, K in elements (= bytes) */
+  const float* a_scale;     /* [M] */
+  const float* b_scale;     /* [N] */
+} v3a_gemm_fp8_args;
+int v3a_gemm_fp8_nt(const v3a_gemm_fp8_args* args, void* stream);
+int v3a_gemm_fp8_num_tiles(void);
+int v3a_gemm_fp8_pick_tile(int M, int N);
+const char* v3a_gemm_fp8_tile_name(int tile);
+int v3a_quantize_fp8_rows(const void* x, void* y, float* scale, long rows, int cols, int ldx, int ldy, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolution (1-D/2-D/3-D, stride, zero or replicate padding, causal-in-time, optional fused nearest-exact 2x

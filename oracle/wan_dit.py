@@ -54,8 +54,24 @@ def _r(x: torch.Tensor, emu: bool) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32) if emu else x
 
 
-def _lin(x, sd, name, emu):
+def quant_rows_e4m3(x: torch.Tensor):
+    """Per-row dynamic e4m3 quantisation as v3a_quantize_fp8_rows does it (NOT part of the reference - the arithmetic of the opt-in
+    fp8 GEMM mode of BASELINE config #4): scale = max(amax, 1e-12) / 448, q = e4m3(clamp(bf16(x) * (1 / scale))), returned as
+    (q in fp32, scale)."""
+    xb = x.to(torch.bfloat16).float()
+    amax = xb.abs().amax(dim=-1, keepdim=True)
+    sc = amax.clamp_min(1e-12) / torch.full_like(amax, 448.0)
+    q = (xb * (torch.ones_like(sc) / sc)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    return q, sc
+
+
+def _lin(x, sd, name, emu, fp8=False):
     w, b = sd[name + ".weight"].float(), sd.get(name + ".bias")
+    if fp8:   # e4m3 operands with per-token / per-output-channel scales, fp32 accumulation, scales applied as one product
+        xq, sx = quant_rows_e4m3(x)
+        wq, sw = quant_rows_e4m3(w)
+        y = (xq @ wq.T) * (sx * sw.reshape(-1))
+        return _r(y if b is None else y + b.float(), emu)
     if emu:
         x, w = _r(x, True), _r(w, True)
     y = F.linear(x, w, None if b is None else b.float())
@@ -125,16 +141,17 @@ def condition_embed(sd, cfg, timestep, text, emu):
     return temb, tproj, ctx
 
 
-def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False):
+def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gemm=False):
+    g8 = fp8_gemm   # the projections of latent tokens (not the per-prompt text K / V) on e4m3 operands
     p = f"blocks.{i}."
     d, H, eps = cfg.dim, cfg.num_attention_heads, cfg.eps
     mod = sd[p + "scale_shift_table"].float() + tproj.float()  # [B,6,d]
     shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = mod.chunk(6, dim=1)
     # 1. self attention
     n = _r(F.layer_norm(x.float(), (d,), eps=eps) * (1 + scale_msa) + shift_msa, emu)
-    q = _lin(n, sd, p + "attn1.to_q", emu)
-    k = _lin(n, sd, p + "attn1.to_k", emu)
-    v = _lin(n, sd, p + "attn1.to_v", emu)
+    q = _lin(n, sd, p + "attn1.to_q", emu, g8)
+    k = _lin(n, sd, p + "attn1.to_k", emu, g8)
+    v = _lin(n, sd, p + "attn1.to_v", emu, g8)
     q = rms_norm(q, sd[p + "attn1.norm_q.weight"], eps)
     k = rms_norm(k, sd[p + "attn1.norm_k.weight"], eps)
     B, N, _ = q.shape
@@ -143,21 +160,21 @@ def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False):
     if fp8_attn:   # MI355X fp8 self-attention mode (see attention_fp8_emulated below): bf16 q, k, v -> e4m3, unit scales
         hs = lambda t: _r(t, True).view(B, N, H, -1).transpose(1, 2)
         ao = attention_fp8_emulated(hs(q), hs(k), hs(v), (d // H) ** -0.5).transpose(1, 2).reshape(B, N, d)
-        a = _lin(_r(ao, emu), sd, p + "attn1.to_out.0", emu)
+        a = _lin(_r(ao, emu), sd, p + "attn1.to_out.0", emu, g8)
     else:
-        a = _lin(attention(q, k, v, H, emu), sd, p + "attn1.to_out.0", emu)
+        a = _lin(attention(q, k, v, H, emu), sd, p + "attn1.to_out.0", emu, g8)
     x = _r(x.float() + a * gate_msa, emu)
     # 2. cross attention (norm2 has affine, no modulation; no mask over zero-padded text rows)
     n = _r(F.layer_norm(x.float(), (d,), sd[p + "norm2.weight"].float(), sd[p + "norm2.bias"].float(), eps), emu)
-    q = rms_norm(_lin(n, sd, p + "attn2.to_q", emu), sd[p + "attn2.norm_q.weight"], eps)
+    q = rms_norm(_lin(n, sd, p + "attn2.to_q", emu, g8), sd[p + "attn2.norm_q.weight"], eps)
     k = rms_norm(_lin(ctx, sd, p + "attn2.to_k", emu), sd[p + "attn2.norm_k.weight"], eps)
     v = _lin(ctx, sd, p + "attn2.to_v", emu)
-    a = _lin(attention(q, k, v, H, emu), sd, p + "attn2.to_out.0", emu)
+    a = _lin(attention(q, k, v, H, emu), sd, p + "attn2.to_out.0", emu, g8)
     x = _r(x + a, emu)
     # 3. feed forward
     n = _r(F.layer_norm(x.float(), (d,), eps=eps) * (1 + c_scale) + c_shift, emu)
-    h = _r(F.gelu(_lin(n, sd, p + "ffn.net.0.proj", emu), approximate="tanh"), emu)
-    f = _lin(h, sd, p + "ffn.net.2", emu)
+    h = _r(F.gelu(_lin(n, sd, p + "ffn.net.0.proj", emu, g8), approximate="tanh"), emu)
+    f = _lin(h, sd, p + "ffn.net.2", emu, g8)
     x = _r(x.float() + f.float() * c_gate, emu)
     return x
 
@@ -179,7 +196,8 @@ def unpatchify(cfg, tokens, Fr, Hh, Ww):
 
 
 def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.Tensor, timestep: torch.Tensor,
-                text: torch.Tensor, emulate_bf16: bool = False, num_layers: int | None = None, fp8_attn: bool = False) -> torch.Tensor:
+                text: torch.Tensor, emulate_bf16: bool = False, num_layers: int | None = None, fp8_attn: bool = False,
+                fp8_gemm: bool = False) -> torch.Tensor:
     """transformer(hidden_states[B,16,T,H,W], timestep[B], encoder_hidden_states[B,L,4096]) -> [B,16,T,H,W]."""
     emu = emulate_bf16
     B, C, Fr, Hh, Ww = latents.shape
@@ -191,7 +209,7 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.T
     temb, tproj, ctx = condition_embed(sd, cfg, timestep, text, emu)
     L = cfg.num_layers if num_layers is None else num_layers
     for i in range(L):
-        x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn)
+        x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn, fp8_gemm)
     shift, scale = (sd["scale_shift_table"].float() + temb.float().unsqueeze(1)).chunk(2, dim=1)
     x = _r(F.layer_norm(x.float(), (cfg.dim,), eps=cfg.eps) * (1 + scale) + shift, emu)
     x = _lin(x, sd, "proj_out", emu)

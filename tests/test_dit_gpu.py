@@ -347,6 +347,41 @@ def test_wan14b_width_fp8_attention_matches_e4m3_oracle(hip_lib, parity):
     assert torch.isfinite(out8.float()).all() and r < 1.5e-2, r
 
 
+def test_wan14b_width_fp8_gemm_matches_e4m3_oracle(hip_lib, parity):
+    """BASELINE config #4 "fp8 GEMMs for the attention/FFN contractions": the block projections on e4m3 operands (per-token /
+    per-output-channel scales) at Wan-14B width against the oracle emulating the same quantisation, alone and together with the
+    fp8 attention; the distance from the bf16 mode is reported as the price of the mode."""
+    from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
+    kw = dict(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=2, text_dim=256, freq_dim=256)
+    ocfg = O.WanDiTConfig(**kw)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=4).items()}
+    model = WanDiT(WanDiTConfig(**kw), sd, device="cuda")
+    g = torch.Generator().manual_seed(14)
+    lat = torch.randn(2, 16, 2, 16, 16, generator=g).to(torch.bfloat16)
+    text = (torch.randn(2, 48, 256, generator=g) * 0.5).to(torch.bfloat16).float()
+    t = torch.tensor([611, 611])
+    out16 = model(lat.cuda(), t.cuda(), text.cuda())[0].clone()
+    model.enable_fp8_gemm()
+    outg = model(lat.cuda(), t.cuda(), text.cuda())[0].clone()
+    refg = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_gemm=True)
+    model.attn_dtype = "fp8"
+    outga = model(lat.cuda(), t.cuda(), text.cuda())[0].clone()
+    refga = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_gemm=True, fp8_attn=True)
+    r1, r2, shift = _rel(outg, refg), _rel(outga, refga), _rel(outga, out16)
+    parity("dit_14B_width_fp8_gemm", rel_vs_e4m3_oracle=r1, rel_with_fp8_attention_vs_e4m3_oracle=r2, rel_fp8_modes_vs_bf16_mode=shift)
+    print(f"14B-width fp8-GEMM forward: rel vs e4m3 oracle {r1:.2e} (+fp8 attention {r2:.2e}); fp8 modes vs bf16 mode {shift:.2e}")
+    # Two pipelines with a discontinuous quantiser between their layers: a 1-ulp bf16 difference in an activation near an e4m3 tie
+    # moves that element by a whole e4m3 step (2^-3 relative), so ~3 % of the quantised elements differ between kernel path and
+    # oracle and the forward can only be bounded to a few e-2 here.  The GEMM itself is pinned on identical quantised operands to
+    # bf16 rounding (< 1.2e-3, bit-identical across tiles) by tests/test_kernels_gpu.py::test_gemm_fp8_every_tile_matches_e4m3_emulation.
+    assert torch.isfinite(outga.float()).all() and r1 < 6e-2 and r2 < 6e-2, (r1, r2)
+    assert shift < 1.5e-1, shift
+    with pytest.raises(NotImplementedError):
+        from vist3a_amd.wan.seqpar import ThreadWorld
+        tw = ThreadWorld(2)
+        tw.run(lambda r: model(lat.cuda(), t.cuda(), text.cuda(), sp=tw.group(r)))
+
+
 @pytest.mark.parametrize("P", [4, 8])
 def test_seq_parallel_production_width_reads_gathered_slabs_in_place(hip_lib, P):
     """Production width and token count (4096 tokens, 2 blocks) over P virtual ranks: every shard holds 4096 / P keys (a multiple of

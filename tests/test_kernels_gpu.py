@@ -484,3 +484,86 @@ def test_attention_fp8_production_shape_and_speed(hip_lib, parity):
     r = relerr(outs[0], ob)
     parity("attention_fp8_vs_bf16_kernel_14B_shape", rel=r)
     assert r < 6e-2, r
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# e4m3 GEMM (BASELINE config #4: "MFMA bf16/fp8 GEMMs for the attention/FFN contractions")
+def _quant_rows_emu(x):
+    """torch restatement of v3a_quantize_fp8_rows (a tensor / python-scalar division would multiply by a reciprocal on the GPU)."""
+    amax = x.float().abs().amax(dim=1)
+    sc = amax.clamp_min(1e-12) / torch.full_like(amax, 448.0)
+    q = (x.float() * (torch.ones_like(sc) / sc)[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q, sc
+
+
+def test_quantize_fp8_rows_is_bit_exact(hip_lib):
+    from vist3a_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    for rows, cols in ((1000, 5120), (257, 13824), (64, 128), (5, 8200)):
+        x = (torch.randn(rows, cols, device=dev, generator=g) * torch.rand(rows, 1, device=dev, generator=g) * 8).to(bf16)
+        x[rows // 2] = 0          # an all-zero row quantises to zeros with the floor scale
+        x[0, 3] = 3.0e4           # one outlier sets its row's scale
+        q, sc = ops.quantize_fp8_rows(x)
+        rq, rsc = _quant_rows_emu(x)
+        assert torch.equal(sc, rsc) and torch.equal(q, rq.view(torch.uint8)), (rows, cols)
+        assert float(sc[rows // 2]) == pytest.approx(1e-12 / 448.0) and int(q[rows // 2].max()) == 0
+
+
+@pytest.mark.parametrize("name,M,N,K,opt", [
+    ("14b_ffn1", 8192, 13824, 5120, dict(act="gelu")),
+    ("14b_ffn2", 8192, 5120, 13824, dict(res_f32=False, scale=True)),
+    ("14b_qk", 8192, 10240, 5120, {}),
+    ("14b_vt", 5120, 8192, 5120, dict(bias_row=True)),
+    ("ragged", 1000, 520, 384, dict(act="gelu")),
+])
+def test_gemm_fp8_every_tile_matches_e4m3_emulation(hip_lib, parity, name, M, N, K, opt):
+    """v3a_gemm_fp8_nt against the same arithmetic in torch (e4m3 values held in fp32, fp32 matmul, scale product, the bf16 GEMM's
+    epilogue): every tile within bf16 output rounding of it and bit-identical to the others."""
+    from vist3a_amd import lib as L, ops
+    lib = L.load()
+    g = torch.Generator(device=dev).manual_seed(K + N)
+    a = torch.randn(M, K, device=dev, generator=g).to(bf16)
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(bf16)
+    bias_row = opt.get("bias_row", False)
+    bias = torch.randn(M if bias_row else N, device=dev, generator=g)
+    act = L.ACT_GELU_TANH if opt.get("act") == "gelu" else L.ACT_NONE
+    res = torch.randn(M, N, device=dev, generator=g).to(bf16) if "res_f32" in opt else None
+    scale = torch.randn(2, N, device=dev, generator=g) if opt.get("scale") else None
+    rpb = M // 2 if scale is not None else 0
+    a8, sa = ops.quantize_fp8_rows(a)
+    w8, sw = ops.quantize_fp8_rows(w)
+    qa, qw = a8.view(torch.float8_e4m3fn).float(), w8.view(torch.float8_e4m3fn).float()
+    v = (qa @ qw.T) * (sa[:, None] * sw[None, :]) + (bias[:, None] if bias_row else bias[None, :])
+    v = v.to(bf16).float()
+    if act:
+        v = torch.nn.functional.gelu(v, approximate="tanh").to(bf16).float()
+    if scale is not None:
+        v = v * scale.repeat_interleave(rpb, dim=0)
+    if res is not None:
+        v = v + res.float()
+    ref = v.to(bf16)
+    exact = a.float() @ w.float().T
+    outs = {}
+    for t in range(lib.v3a_gemm_fp8_num_tiles()):
+        nm = lib.v3a_gemm_fp8_tile_name(t).decode()
+        outs[nm] = ops.gemm(a8, w8, bias, act=act, residual=res, scale=scale, rows_per_batch=rpb, bias_row=bias_row, a_scale=sa,
+                            w_scale=sw, tile=t)
+    auto = ops.gemm(a8, w8, bias, act=act, residual=res, scale=scale, rows_per_batch=rpb, bias_row=bias_row, a_scale=sa, w_scale=sw)
+    first = next(iter(outs.values()))
+    worst = max(relerr(o, ref) for o in outs.values())
+    quant_cost = relerr((qa @ qw.T) * (sa[:, None] * sw[None, :]), exact)
+    parity(f"gemm_fp8_{name}", M=M, N=N, K=K, rel_vs_e4m3_emulation=worst, rel_e4m3_operands_vs_bf16_operands=quant_cost)
+    assert all(torch.equal(o, first) for o in outs.values()) and torch.equal(auto, first)
+    assert worst < 1.2e-3, worst            # bf16 output rounding flips (fp32 accumulation order differs from torch's)
+    assert quant_cost < 5e-2, quant_cost    # what 3 mantissa bits on both operands cost
+
+
+def test_gemm_fp8_rejects_bad_arguments(hip_lib):
+    from vist3a_amd import lib as L, ops
+    a8 = torch.zeros(256, 192, device=dev, dtype=torch.uint8)       # K % 128 != 0
+    w8 = torch.zeros(64, 192, device=dev, dtype=torch.uint8)
+    s = torch.ones(256, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a8, w8, None, a_scale=s, w_scale=s[:64].contiguous())
+    with pytest.raises(ValueError):
+        ops.gemm(a8[:, :128].contiguous(), w8[:, :128].contiguous(), None, a_scale=s[:5].contiguous(), w_scale=s[:64].contiguous())

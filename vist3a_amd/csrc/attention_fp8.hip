@@ -21,7 +21,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 struct Attn8P {
   const char* q; const char* k; const char* vt; char* o;
@@ -253,7 +252,68 @@ __global__ __launch_bounds__(256) void quantize_fp8_kernel(const QuantP p) {
   *(u32x4*)(p.y + (size_t)r * p.ldy + c) = o;
 }
 
+// one wave per row: amax, then the scaled e4m3 image.  The row is held in registers between the two steps when it fits (cols <= 8192).
+struct QuantRowsP { const char* x; char* y; float* scale; long rows; int cols, ldx, ldy; };
+__global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const QuantRowsP p) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.rows) return;
+  const char* src = p.x + (size_t)r * p.ldx * 2;
+  const int nch = p.cols / 8;   // 16-byte chunks of 8 bf16
+  constexpr int HOLD = 16;      // chunks per lane kept in registers
+  u32x4 held[HOLD];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < HOLD; ++i) {
+    const int c = i * 64 + lane;
+    held[i] = c < nch ? *(const u32x4*)(src + (size_t)c * 16) : u32x4{0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int i = 0; i < HOLD; ++i) {
+    float f[8];
+    unpack_bf16x8(held[i], f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(f[k]));
+  }
+  for (int c = HOLD * 64 + lane; c < nch; c += 64) {
+    float f[8];
+    unpack_bf16x8(*(const u32x4*)(src + (size_t)c * 16), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(f[k]));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float sc = fmaxf(amax, 1e-12f) / 448.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) p.scale[r] = sc;
+  char* dst = p.y + (size_t)r * p.ldy;
+  auto emit = [&](const u32x4 v, int c) {
+    float f[8];
+    unpack_bf16x8(v, f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = fminf(fmaxf(f[k] * inv, -448.f), 448.f);
+    u32x2 o;
+    o[0] = (unsigned)pack_fp8x4(f[0], f[1], f[2], f[3]);
+    o[1] = (unsigned)pack_fp8x4(f[4], f[5], f[6], f[7]);
+    *(u32x2*)(dst + (size_t)c * 8) = o;
+  };
+#pragma unroll
+  for (int i = 0; i < HOLD; ++i) {
+    const int c = i * 64 + lane;
+    if (c < nch) emit(held[i], c);
+  }
+  for (int c = HOLD * 64 + lane; c < nch; c += 64) emit(*(const u32x4*)(src + (size_t)c * 16), c);
+}
+
 }  // namespace
+
+extern "C" int v3a_quantize_fp8_rows(const void* x, void* y, float* scale, long rows, int cols, int ldx, int ldy, void* stream) {
+  if (!x || !y || !scale) return V3A_ERR_ARG;
+  if (rows <= 0 || cols <= 0 || cols % 8 || ldx % 8 || ldy % 8 || ldx < cols || ldy < cols) return V3A_ERR_SHAPE;
+  hipLaunchKernelGGL(quantize_fp8_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     QuantRowsP{(const char*)x, (char*)y, scale, rows, cols, ldx, ldy});
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}
 
 extern "C" int v3a_quantize_fp8(const void* x, void* y, long rows, int cols, int ldx, int ldy, float scale, void* stream) {
   if (!x || !y) return V3A_ERR_ARG;

@@ -10,6 +10,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumu
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(8))) int i32x8;         // 32 e4m3 = one 32x32x64 f8f6f4 MFMA A/B fragment (8 VGPR)
 
 #define V3A_OK 0
 #define V3A_ERR_ARG (-1)

@@ -44,6 +44,9 @@ struct GemmP {
   int pT, pH, pW;         // leading pad (trailing implied by the output extent)
   int ups;                // 1: taps address a nearest-exact 2x (H,W) upsample of the stored input
   int replicate;          // 1: clamp out-of-range taps (padding_mode="replicate"), 0: zero
+  // e4m3 operands (gemm_pp_kernel<.., F8 = true> only): per-row dequantisation scales of A and B (fp32), applied to the accumulators
+  const float* a_scale;   // [M]
+  const float* b_scale;   // [N]
 };
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -84,6 +87,35 @@ struct EpiAux {
   const char* lds_scale = nullptr;   // f32 [tile columns] of the tile's (single) batch row of `scale`
   int m0 = 0, n0 = 0;
 };
+
+// two 16-byte LDS fragments -> the 8-VGPR operand of the f8f6f4 MFMA
+__device__ __forceinline__ i32x8 frag8(const u32x4 a, const u32x4 b) {
+  i32x8 r;
+  r[0] = (int)a[0]; r[1] = (int)a[1]; r[2] = (int)a[2]; r[3] = (int)a[3];
+  r[4] = (int)b[0]; r[5] = (int)b[1]; r[6] = (int)b[2]; r[7] = (int)b[3];
+  return r;
+}
+
+// e4m3 GEMM: acc *= a_scale[m] * b_scale[n] (the product is formed first, in fp32), ahead of the bias.
+template <int MT, int NTL>
+__device__ __forceinline__ void gemm_dequant(const GemmP& p, f32x16 (&acc)[MT][NTL], int lane, int mw0, int nw) {
+  const int hi = lane >> 5, l31 = lane & 31;
+  float sa[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) sa[i] = p.a_scale[min(mw0 + i * 32 + l31, p.M - 1)];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {   // one 32-column block at a time: with all NTL blocks' scales live the 256x256 tile spills
+    f32x4 sb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sb[g] = *(const f32x4*)(p.b_scale + min(nw + j * 32 + g * 8 + hi * 4, p.N - 4));
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][g * 4 + e] *= sa[i] * sb[g][e];
+  }
+}
 
 // Epilogue shared by every main loop: the wave owns an (MT*32) x (NTL*32) output tile whose 32x32 blocks sit in acc[i][j] in
 // D^T orientation (lane (l31, hi) holds rows m = l31, 4 consecutive columns per accumulator quad).  Per 32-row group:
@@ -614,7 +646,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 //
 // ABL (development ablations, -DV3A_GEMM_ABL builds only; results are garbage): bit 0 = no LDS-DMA in the K loop, bit 1 = no
 // fragment reads, bit 2 = no MFMAs, bit 3 = no s_setprio.
-template <int NP, bool RA, int LEAD, int ABL = 0>
+template <int NP, bool RA, int LEAD, int ABL = 0, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
   using T = PPCfg<NP>;
   constexpr int RB = T::RB, STAGE = T::STAGE, J = T::J;
@@ -699,6 +731,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
 
   f32x16 acc[MT][NTL];
   bf16x8 rf[2][4] = {}, sf[4] = {};
+  i32x8 rf8[2][2] = {}, sf8[2] = {};   // F8 form of the same fragments
   // counted wait for the data of phase nc of a tile with nrem tiles left (including itself); exact in the tail, where fewer
   // instructions than the steady-state count are outstanding behind the needed ones
   auto wait_phase = [&](auto nc_tag, int nrem) {
@@ -721,14 +754,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     } else {
       const char* sR = smem + BUF * STAGE + roff;
       const char* sS = smem + BUF * STAGE + soff;
-      if constexpr (c == 0) {
+      if constexpr (F8) {   // the same eight 16-byte reads, landing pairwise in the 8-VGPR operands of the f8f6f4 MFMA
+        if constexpr (c == 0) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+              rf8[b][s2] = frag8(*(const u32x4*)(sR + b * 32 * RB + koff[2 * s2]), *(const u32x4*)(sR + b * 32 * RB + koff[2 * s2 + 1]));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          sf8[s2] = frag8(*(const u32x4*)(sS + c * 32 * RB + koff[2 * s2]), *(const u32x4*)(sS + c * 32 * RB + koff[2 * s2 + 1]));
+      } else if constexpr (c == 0) {
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) rf[b][ks] = *(const bf16x8*)(sR + b * 32 * RB + koff[ks]);
       }
+      if constexpr (!F8) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) sf[ks] = *(const bf16x8*)(sS + c * 32 * RB + koff[ks]);
+        for (int ks = 0; ks < 4; ++ks) sf[ks] = *(const bf16x8*)(sS + c * 32 * RB + koff[ks]);
+      }
     }
   };
   auto mfma_phase = [&](auto c_tag) {
@@ -736,7 +782,25 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!(ABL & 8)) __builtin_amdgcn_s_setprio(1);
-    if constexpr (!(ABL & 4)) {
+    if constexpr (F8) {
+      // e4m3 operands: the same 128-byte rows now hold 128 k values; one v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales) eats
+      // two of the bf16 loop's 16-byte fragments per lane.  A and B agree on which k each (lane half, byte) carries, which is all
+      // the instruction needs, so the LDS image, swizzle and fragment reads are those of the bf16 loop.
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if constexpr (RA) acc[b][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(sf8[s2], rf8[b][s2], acc[b][c], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          else acc[c][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(rf8[b][s2], sf8[s2], acc[c][b], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+      // the scaled-MFMA intrinsic is a pure call to the optimiser, which otherwise sinks whole phases of them to the next use of the
+      // accumulator (several barriers later) and keeps every fragment alive until then: pin the results here
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if constexpr (RA) asm volatile("" : "+v"(acc[b][c]));
+        else asm volatile("" : "+v"(acc[c][b]));
+      }
+    } else if constexpr (!(ABL & 4)) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -845,6 +909,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
     // every fragment read has returned (lgkmcnt(0) precedes the last MFMAs) and no DMA is in flight (the tail waits reach 0):
     // both stages are free
     const int em = m0 + (RA ? wr * 64 : ws * 32 * NP), en = n0 + (RA ? ws * 32 * NP : wr * 64);
+    if constexpr (F8) gemm_dequant<MT, NTL>(p, acc, lane, em, en);
     if constexpr (!(ABL & 32) && !(ABL & 128)) gemm_add_bias<MT, NTL>(p, acc, lane, em, en, aux);
     gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8), (ABL >> 4) & 15>(p, acc, smem, wave, lane, em, en, aux);
   }
@@ -891,6 +956,14 @@ const TileEntry kTiles[] = {
 #endif
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+// e4m3 forms of the ping-pong tiles (K tile = 128 elements: the same bytes per row, twice the matrix rate)
+#define PP8_ENTRY(NP, RA, LEAD)                                                                     \
+  { "pp8_np" #NP "_ra" #RA "_l" #LEAD, (RA) ? 256 : 64 * NP, (RA) ? 64 * NP : 256, 512, PPCfg<NP>::LDS_BYTES, \
+    (gemm_fn)gemm_pp_kernel<NP, RA, LEAD, 0, true>, nullptr }
+// (the 256x256 form spills in its epilogue and measured slower on every Wan-14B / 1.3B shape: not instantiated)
+const TileEntry kTilesF8[] = {PP8_ENTRY(3, true, 5), PP8_ENTRY(3, false, 5)};
+constexpr int kNumTilesF8 = 2;
+int g_attr_lds_f8[kNumTilesF8] = {};
 int g_attr_lds[kNumTiles][2] = {};
 
 // tiles the heuristic may choose from (the rest are explicit / tuning variants); the ping-pong tiles have no conv form
@@ -934,6 +1007,30 @@ int launch(const GemmP& p, int ti, bool conv, void* stream) {
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
+int pick_tile_f8(int M, int N) {
+  double best = 1e30;
+  int bi = 0;
+  for (int i = 0; i < kNumTilesF8; ++i) {
+    const TileEntry& e = kTilesF8[i];
+    const long tiles = (long)((M + e.BM - 1) / e.BM) * ((N + e.BN - 1) / e.BN);
+    const double cost = (double)((tiles + 255) / 256) * e.BM * e.BN;
+    if (cost < best - 1e-9) { best = cost; bi = i; }
+  }
+  return bi;
+}
+
+int launch_f8(const GemmP& p, int ti, void* stream) {
+  if (ti < 0 || ti >= kNumTilesF8) ti = pick_tile_f8(p.M, p.N);
+  const TileEntry& e = kTilesF8[ti];
+  if (g_attr_lds_f8[ti] < e.lds) {
+    if (hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, e.lds) != hipSuccess) return V3A_ERR_LAUNCH;
+    g_attr_lds_f8[ti] = e.lds;
+  }
+  const long tiles = (long)((p.M + e.BM - 1) / e.BM) * ((p.N + e.BN - 1) / e.BN);
+  hipLaunchKernelGGL(e.fn, dim3((unsigned)tiles), dim3(e.nthr), e.lds, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}
+
 constexpr int kKnownFlags = V3A_GEMM_BIAS_ROW | V3A_GEMM_SCALE_PER_BATCH | V3A_GEMM_ROUND_AFTER_SCALE | V3A_GEMM_RES_F32 |
                             V3A_GEMM_OUT_F32 | V3A_GEMM_NO_ROUND_ACC | V3A_GEMM_RELU_OUT;
 
@@ -962,6 +1059,35 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
   if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
   return launch(p, a->tile, false, stream);
+}
+
+extern "C" int v3a_gemm_fp8_num_tiles(void) { return kNumTilesF8; }
+extern "C" int v3a_gemm_fp8_pick_tile(int M, int N) { return (M > 0 && N > 0) ? pick_tile_f8(M, N) : V3A_ERR_SHAPE; }
+extern "C" const char* v3a_gemm_fp8_tile_name(int t) { return (t >= 0 && t < kNumTilesF8) ? kTilesF8[t].name : ""; }
+
+extern "C" int v3a_gemm_fp8_nt(const v3a_gemm_fp8_args* f, void* stream) {
+  if (!f) return V3A_ERR_ARG;
+  const v3a_gemm_args* a = &f->g;
+  if (!a->A || !a->B || !a->C || !f->a_scale || !f->b_scale) return V3A_ERR_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return V3A_ERR_SHAPE;
+  if (a->K % 128 || a->lda % 16 || a->ldb % 16 || a->ldc % 8 || a->N % 8) return V3A_ERR_SHAPE;
+  if (a->residual && (a->ldr % 8)) return V3A_ERR_SHAPE;
+  if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
+  if ((a->flags & V3A_GEMM_SCALE_PER_BATCH) && a->scale && a->rows_per_batch <= 0) return V3A_ERR_ARG;
+  if (a->flags & ~kKnownFlags) return V3A_ERR_ARG;
+  if (a->flags & V3A_GEMM_NO_ROUND_ACC) return V3A_ERR_ARG;
+  GemmP p = {};
+  p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C;
+  p.bias = a->bias; p.res = (const char*)a->residual; p.scale = a->scale;
+  // the main loop addresses operands in 2-byte units: an e4m3 row of K elements is a bf16 row of K / 2
+  p.M = a->M; p.N = a->N; p.K = a->K / 2;
+  p.lda = a->lda / 2; p.ldb = a->ldb / 2; p.ldc = a->ldc; p.ldr = a->ldr;
+  p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : 1; p.sstride = a->scale_stride;
+  p.act = a->act; p.flags = a->flags;
+  p.res2 = (const char*)a->residual2; p.ldr2 = a->ldr2; p.res_mod = a->res_row_mod;
+  p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
+  p.a_scale = f->a_scale; p.b_scale = f->b_scale;
+  return launch_f8(p, a->tile, stream);
 }
 
 extern "C" int v3a_conv_bf16(const v3a_conv_args* a, void* stream) {

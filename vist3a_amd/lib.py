@@ -98,6 +98,10 @@ class AttnArgs(C.Structure):
     ]
 
 
+class GemmFp8Args(C.Structure):
+    _fields_ = [("g", GemmArgs), ("a_scale", C.c_void_p), ("b_scale", C.c_void_p)]
+
+
 class AttnFp8Args(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p),
@@ -153,6 +157,11 @@ SYMBOLS = {
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "v3a_attention_fwd_fp8": (C.c_int, [C.POINTER(AttnFp8Args), C.c_void_p]),
+    "v3a_gemm_fp8_nt": (C.c_int, [C.POINTER(GemmFp8Args), C.c_void_p]),
+    "v3a_gemm_fp8_num_tiles": (C.c_int, []),
+    "v3a_gemm_fp8_pick_tile": (C.c_int, [C.c_int, C.c_int]),
+    "v3a_gemm_fp8_tile_name": (C.c_char_p, [C.c_int]),
+    "v3a_quantize_fp8_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "v3a_quantize_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "v3a_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "v3a_rmsnorm_rope": (C.c_int, [C.POINTER(RmsNormRopeArgs), C.c_void_p]),

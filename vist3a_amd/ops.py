@@ -37,8 +37,8 @@ class GemmProbe:
     """Optional HIP-event instrumentation of the GEMM launches that resolve to one tile configuration (= one kernel symbol):
     accumulates algorithmic FLOPs and event pairs so bench.py can report that kernel's live roofline numbers."""
 
-    def __init__(self, tile: int):
-        self.tile, self.flops, self.events, self.active = tile, 0.0, [], False
+    def __init__(self, tile: int, fp8: bool = False):
+        self.tile, self.fp8, self.flops, self.events, self.active = tile, fp8, 0.0, [], False
 
     def summary(self):
         torch.cuda.synchronize()
@@ -74,13 +74,17 @@ def gemm(
     res_row_mod: int = 0,
     relu_out: bool = False,
     out_rows: Optional[tuple] = None,
+    a_scale: Optional[torch.Tensor] = None,
+    w_scale: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T); see v3a_gemm_bf16_nt for the epilogue order.
     out_rows=(group, skip, off) scatters output row m to m + (m//group)*skip + off (out must be given).
 
-    scale: f32 [N] (LayerScale) or [nbatch, N] together with rows_per_batch (AdaLN gate)."""
-    _chk2d(a, "a", (bf16,))
-    _chk2d(w, "w", (bf16,))
+    scale: f32 [N] (LayerScale) or [nbatch, N] together with rows_per_batch (AdaLN gate).
+    a_scale / w_scale (f32 [M] / [N]): a and w are e4m3 bytes from `quantize_fp8_rows`; runs v3a_gemm_fp8_nt (tile then indexes its tiles)."""
+    in_dt = (bf16,) if a_scale is None else (torch.uint8, torch.float8_e4m3fn)
+    _chk2d(a, "a", in_dt)
+    _chk2d(w, "w", in_dt)
     M, K = a.shape
     N, K2 = w.shape
     if K != K2:
@@ -91,7 +95,7 @@ def gemm(
         out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
     _chk2d(out, "out", (f32,) if out_f32 else (bf16,))
     # weight-streaming shapes (<= 128 rows against a big matrix) go to the skinny kernel: the tile GEMM would occupy N/128 CUs
-    plain = scale is None and residual2 is None and out_rows is None and not relu_out and tile < 0 and res_row_mod == 0
+    plain = a_scale is None and scale is None and residual2 is None and out_rows is None and not relu_out and tile < 0 and res_row_mod == 0
     if plain and K % 512 == 0 and K >= 1024:
         if M <= 128 and N >= 512 and not bias_row:
             return _gemm_skinny(a, w, bias, out, act, residual, out_f32, transposed=False)
@@ -131,8 +135,24 @@ def gemm(
         _ptr(residual2), residual2.stride(0) if residual2 is not None else 0, res_row_mod,
         *(out_rows if out_rows is not None else (0, 0, 0)),
     )
+    if a_scale is not None:
+        for t, n, nm in ((a_scale, M, "a_scale"), (w_scale, N, "w_scale")):
+            if t is None or t.dtype != f32 or not t.is_contiguous() or t.numel() != n:
+                raise ValueError(f"{nm} must be contiguous f32 of length {n}")
+        fargs = L.GemmFp8Args(args, _ptr(a_scale), _ptr(w_scale))
+        pr = _probe
+        timed = pr is not None and pr.active and pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_fp8_pick_tile(M, N)) == pr.tile
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(L.load().v3a_gemm_fp8_nt(C.byref(fargs), _stream()), "v3a_gemm_fp8_nt")
+        if timed:
+            e1.record()
+            pr.events.append((e0, e1))
+            pr.flops += 2.0 * M * N * K
+        return out
     pr = _probe
-    if pr is not None and pr.active and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile(M, N)) == pr.tile:
+    if pr is not None and pr.active and not pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile(M, N)) == pr.tile:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")
@@ -307,6 +327,18 @@ def quantize_fp8(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor
         raise ValueError("out must be a uint8 [rows, cols] tensor with a contiguous last dim")
     L.check(L.load().v3a_quantize_fp8(_ptr(x), _ptr(out), rows, cols, x.stride(0), out.stride(0), float(scale), _stream()), "v3a_quantize_fp8")
     return out
+
+
+def quantize_fp8_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
+    """(e4m3 bytes [rows, cols], f32 [rows]): per-row dynamic quantisation, scale = max(amax, 1e-12) / 448 (v3a_quantize_fp8_rows)."""
+    _chk2d(x, "x", (bf16,))
+    rows, cols = x.shape
+    out = torch.empty((rows, cols), device=x.device, dtype=torch.uint8) if out is None else out
+    scale = torch.empty(rows, device=x.device, dtype=f32) if scale is None else scale
+    if out.dtype not in (torch.uint8, torch.float8_e4m3fn) or out.stride(1) != 1 or scale.dtype != f32 or not scale.is_contiguous() or scale.numel() != rows:
+        raise ValueError("out must be bytes with unit inner stride, scale contiguous f32 [rows]")
+    L.check(L.load().v3a_quantize_fp8_rows(_ptr(x), _ptr(out), _ptr(scale), rows, cols, x.stride(0), out.stride(0), _stream()), "v3a_quantize_fp8_rows")
+    return out, scale
 
 
 def attention_fp8(q8: torch.Tensor, k8: torch.Tensor, vt8: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Nq: int, Nk: int,

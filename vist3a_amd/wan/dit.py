@@ -107,6 +107,7 @@ class _Workspace:
             self.qk = e(M, 2 * d)
             self.vt = torch.zeros(d, B * ((N + 63) // 64 * 64), device=device, dtype=bf16)
             self.qk8 = self.vt8 = None   # e4m3 copies, allocated on first use of the fp8 attention mode
+            self.a8 = self.sa = self.h8 = self.sh = None   # e4m3 activations + per-token scales of the fp8 GEMM mode
         else:  # sequence-parallel: local q, packed local [K | V^T] to send, gathered slabs, full K / V^T
             self.q = e(M, d)
             self.pack = e(2 * M * d)
@@ -132,7 +133,24 @@ class WanDiT:
         # and V^T are rounded to e4m3 with the unit scales below.  "bf16" (default) is the reference's precision.
         self.attn_dtype = "bf16"
         self.fp8_scales = (1.0, 1.0, 1.0)
+        # "fp8" (set by enable_fp8_gemm): the block projections of latent tokens (q/k/v/o, cross q/o, FFN) on e4m3 operands
+        # (v3a_gemm_fp8_nt), activations quantised per token and weights per output channel; single-GPU path only.
+        self.gemm_dtype = "bf16"
         self._load(state_dict)
+
+    _FP8_WEIGHTS = ("wqk", "wv", "wo", "wq2", "wo2", "w1", "w2")
+
+    def enable_fp8_gemm(self) -> "WanDiT":
+        """Quantise the block projection weights to e4m3 with one scale per output channel (kept beside the bf16 weights, which the
+        sequence-parallel path and the per-prompt text K / V projections still use) and switch the block GEMMs to v3a_gemm_fp8_nt."""
+        if self.cfg.dim % 128 or self.cfg.ffn_dim % 128:
+            raise ValueError("fp8 GEMMs need K % 128 == 0")
+        for b in self.blocks:
+            for k in self._FP8_WEIGHTS:
+                if k + "8" not in b:
+                    b[k + "8"], b["s" + k] = ops.quantize_fp8_rows(b[k])
+        self.gemm_dtype = "fp8"
+        return self
 
     # ---------------------------------------------------------------- weights
     def _load(self, sd):
@@ -274,13 +292,38 @@ class WanDiT:
         else:
             kl, vtl = ws.pack[:Ml * d].view(Ml, d), ws.pack[Ml * d:].view(d, Ml)
             vt_full = ws.vt[:, :B * N]
+        g8 = self.gemm_dtype == "fp8"
+        if g8:
+            if P != 1:
+                raise NotImplementedError("the fp8 GEMM mode covers the single-GPU path")
+            if ws.a8 is None:
+                ws.a8, ws.sa = torch.empty(Ml, d, device=self.device, dtype=torch.uint8), torch.empty(Ml, device=self.device, dtype=f32)
+                ws.h8, ws.sh = torch.empty(Ml, cfg.ffn_dim, device=self.device, dtype=torch.uint8), torch.empty(Ml, device=self.device, dtype=f32)
+
+        def lin(a, b, w, bias, **kw):
+            """a @ b[w]^T (+ epilogue): bf16, or e4m3 after a per-token quantisation pass over `a`"""
+            if not g8:
+                return ops.gemm(a, b[w], bias, **kw)
+            a8, sa = (ws.h8, ws.sh) if a is ws.h else (ws.a8, ws.sa)
+            if a is not lin.last:   # the q/k and V^T projections share one quantised copy of the normed tokens
+                ops.quantize_fp8_rows(a, a8, sa)
+                lin.last = a
+            return ops.gemm(a8, b[w + "8"], bias, a_scale=sa, w_scale=b["s" + w], **kw)
+        lin.last = None
+
         for li in range(nl):
             b, m = self.blocks[li], mod[li]
             # --- self attention
             ops.layernorm(x, out=ws.n, scale=m[:, 1], shift=m[:, 0], rows_per_batch=Nl, eps=cfg.eps)
+            lin.last = None
             if P == 1:
-                ops.gemm(ws.n, b["wqk"], b["bqk"], out=ws.qk)
-                if vbs == N:  # no per-item padding: V^T of the whole batch is one [d, B*N] GEMM (256 tiles of 192x256 at 1.3B)
+                lin(ws.n, b, "wqk", b["bqk"], out=ws.qk)
+                if g8:   # V^T = Wv . X^T: the weight rows are the GEMM's A side
+                    for bi in range(B if vbs != N else 1):
+                        r0, r1 = (0, Ml) if vbs == N else (bi * N, (bi + 1) * N)
+                        ops.gemm(b["wv8"], ws.a8[r0:r1], b["bv"], out=ws.vt if vbs == N else ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True,
+                                 a_scale=b["swv"], w_scale=ws.sa[r0:r1])
+                elif vbs == N:  # no per-item padding: V^T of the whole batch is one [d, B*N] GEMM (256 tiles of 192x256 at 1.3B)
                     ops.gemm(b["wv"], ws.n, b["bv"], out=ws.vt, bias_row=True)
                 else:
                     for bi in range(B):
@@ -319,19 +362,23 @@ class WanDiT:
                     vt_full.view(d, B, P, Nl).copy_(ws.gbuf[:, Ml * d:].view(P, d, B, Nl).permute(1, 2, 0, 3))
                     ops.attention(ws.q, ws.kfull, ws.vt, ws.ao, B=B, H=H, Nq=Nl, Nk=N, D=hd, q_batch_stride=Nl * d,
                                   k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=Nl * d)
-            ops.gemm(ws.ao, b["wo"], b["bo"], out=x, residual=x, scale=m[:, 2], rows_per_batch=Nl)
+            lin.last = None
+            lin(ws.ao, b, "wo", b["bo"], out=x, residual=x, scale=m[:, 2], rows_per_batch=Nl)
             # --- cross attention
             ops.layernorm(x, out=ws.n, weight=b["n2w"], bias=b["n2b"], eps=cfg.eps)
-            ops.gemm(ws.n, b["wq2"], b["bq2"], out=ws.q2)
+            lin.last = None
+            lin(ws.n, b, "wq2", b["bq2"], out=ws.q2)
             ops.rmsnorm_rope(ws.q2, b["nq2"], out=ws.q2, eps=cfg.eps)
             ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lk, D=hd, q_batch_stride=Nl * d,
                           k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d, key_bias=kbias if merged else None,
                           key_bias_first=Lk - 1)
-            ops.gemm(ws.ao, b["wo2"], b["bo2"], out=x, residual=x)
+            lin.last = None
+            lin(ws.ao, b, "wo2", b["bo2"], out=x, residual=x)
             # --- feed forward
             ops.layernorm(x, out=ws.n, scale=m[:, 4], shift=m[:, 3], rows_per_batch=Nl, eps=cfg.eps)
-            ops.gemm(ws.n, b["w1"], b["b1"], out=ws.h, act=L.ACT_GELU_TANH)
-            ops.gemm(ws.h, b["w2"], b["b2"], out=x, residual=x, scale=m[:, 5], rows_per_batch=Nl)
+            lin.last = None
+            lin(ws.n, b, "w1", b["b1"], out=ws.h, act=L.ACT_GELU_TANH)
+            lin(ws.h, b, "w2", b["b2"], out=x, residual=x, scale=m[:, 5], rows_per_batch=Nl)
 
         om = (self.out_sst[None] + temb.float()[:, None]).contiguous()  # [B,2,d]
         ops.layernorm(x, out=ws.n, scale=om[:, 1], shift=om[:, 0], rows_per_batch=Nl, eps=cfg.eps)
