@@ -190,6 +190,8 @@ typedef struct {
   int in_row_group, in_row_skip, in_row_off;    /* group > 0: logical row m reads x row m + (m/group)*skip + off */
   int out_row_group, out_row_skip, out_row_off; /* same for the output (gather/scatter of per-frame token blocks) */
   int rms;                                      /* 1: RMS norm, no mean subtraction (T5LayerNorm of the UMT5 text encoder) */
+  float* y_fp8_scale;                           /* non-NULL: y is e4m3 BYTES [rows][ldy] = v3a_quantize_fp8_rows of the bf16 result, its
+                                                   per-row scales written here (fp8 GEMM mode: saves the separate quantisation pass) */
 } v3a_layernorm_args;
 int v3a_layernorm(const v3a_layernorm_args* args, void* stream);
 

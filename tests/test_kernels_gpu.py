@@ -567,3 +567,23 @@ def test_gemm_fp8_rejects_bad_arguments(hip_lib):
         ops.gemm(a8, w8, None, a_scale=s, w_scale=s[:64].contiguous())
     with pytest.raises(ValueError):
         ops.gemm(a8[:, :128].contiguous(), w8[:, :128].contiguous(), None, a_scale=s[:5].contiguous(), w_scale=s[:64].contiguous())
+
+
+def test_layernorm_fp8_output_equals_separate_quantisation_pass(hip_lib):
+    """v3a_layernorm with y_fp8_scale: bit-identical to LayerNorm -> bf16 followed by v3a_quantize_fp8_rows (AdaLN and affine forms,
+    fp32 and bf16 inputs, a width that is not a multiple of 512)."""
+    from vist3a_amd import ops
+    g = torch.Generator(device=dev).manual_seed(9)
+    for (M, d, rpb, xf32) in [(8192, 5120, 4096, True), (1000, 1536, 500, False), (37, 1000, 37, True)]:
+        x = (torch.randn(M, d, device=dev, generator=g) * 3 + 0.25)
+        x = x if xf32 else x.to(bf16)
+        nb = (M + rpb - 1) // rpb
+        sc, sh = torch.randn(nb, d, device=dev, generator=g) * 0.3, torch.randn(nb, d, device=dev, generator=g) * 0.3
+        w, b = torch.randn(d, device=dev, generator=g), torch.randn(d, device=dev, generator=g)
+        for kw in (dict(scale=sc, shift=sh, rows_per_batch=rpb), dict(weight=w, bias=b)):
+            y = ops.layernorm(x, eps=1e-6, **kw)
+            q_ref, s_ref = ops.quantize_fp8_rows(y)
+            q = torch.empty(M, d, device=dev, dtype=torch.uint8)
+            s = torch.empty(M, device=dev)
+            ops.layernorm(x, out=q, fp8_scale=s, eps=1e-6, **kw)
+            assert torch.equal(s, s_ref) and torch.equal(q, q_ref), (M, d, list(kw))

@@ -20,6 +20,7 @@ struct LnP {
   int x_f32, y_f32;
   int ig, is, io, og, os, oo;   // row remaps: in row = m + (m/ig)*is + io (ig>0), out row likewise
   int rms;                      // 1: no mean subtraction
+  float* y_scale;               // non-null: e4m3 output with per-row dynamic scale
 };
 
 template <int CPL>
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)p.d + p.eps);
   const size_t moff = (size_t)(row0 / p.rpb) * p.mstride;
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
     const int c = lane + i * 64;
@@ -87,7 +89,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[e] = o[e] * (1.f + s0[e]) + h0[e]; o[4 + e] = o[4 + e] * (1.f + s1[e]) + h1[e]; }
     }
-    if (p.y_f32) {
+    if (p.y_scale) {   // keep the bf16-rounded result in registers; the row maximum decides the e4m3 scale below
+      unpack_bf16x8(pack_bf16x8(o), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+    } else if (p.y_f32) {
       float* yp = (float*)p.y + orow * p.ldy + c * 8;
       f32x4 a, bq;
 #pragma unroll
@@ -96,6 +102,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
       *(f32x4*)(yp + 4) = bq;
     } else {
       *(u32x4*)(p.y + (orow * p.ldy + c * 8) * 2) = pack_bf16x8(o);
+    }
+  }
+  if (p.y_scale) {   // same arithmetic as quantize_fp8_rows_kernel (attention_fp8.hip) on the bf16 row
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float sc = fmaxf(amax, 1e-12f) / 448.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) p.y_scale[orow] = sc;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const int c = lane + i * 64;
+      if (c >= nch) continue;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(v[i][e] * inv, -448.f), 448.f);
+      u32x2 q;
+      q[0] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false), true);
+      q[1] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false), true);
+      *(u32x2*)(p.y + orow * p.ldy + c * 8) = q;
     }
   }
 }
@@ -273,6 +298,8 @@ extern "C" int v3a_layernorm(const v3a_layernorm_args* a, void* stream) {
   p.ig = a->in_row_group; p.is = a->in_row_skip; p.io = a->in_row_off;
   p.og = a->out_row_group; p.os = a->out_row_skip; p.oo = a->out_row_off;
   p.rms = a->rms;
+  p.y_scale = a->y_fp8_scale;
+  if (p.y_scale && p.y_f32) return V3A_ERR_ARG;
   const dim3 grid((a->M + 3) / 4);
   DISPATCH_CPL(layernorm_kernel, p, a->d, grid, stream);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;

@@ -125,6 +125,7 @@ class LayerNormArgs(C.Structure):
         ("in_row_group", C.c_int), ("in_row_skip", C.c_int), ("in_row_off", C.c_int),
         ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
         ("rms", C.c_int),
+        ("y_fp8_scale", C.c_void_p),
     ]
 
 

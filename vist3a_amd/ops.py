@@ -361,16 +361,23 @@ def layernorm(
     scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
     rows_per_batch: int = 0, eps: float = 1e-6, out_dtype: torch.dtype = bf16,
     M: Optional[int] = None, in_rows: tuple = (0, 0, 0), out_rows: tuple = (0, 0, 0), rms: bool = False,
+    fp8_scale: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """in_rows/out_rows = (group, skip, off): logical row m maps to physical row m + (m//group)*skip + off.
-    rms=True: no mean subtraction (T5LayerNorm)."""
+    rms=True: no mean subtraction (T5LayerNorm).
+    fp8_scale (f32 [rows of out]): `out` is e4m3 bytes, the per-row quantisation (ops.quantize_fp8_rows) of the bf16 result."""
     _chk2d(x, "x", (bf16, f32))
     d = x.shape[1]
     if M is None:
         M = x.shape[0]
     if out is None:
         out = torch.empty((M, d), device=x.device, dtype=out_dtype)
-    _chk2d(out, "out", (bf16, f32))
+    if fp8_scale is not None:
+        _chk2d(out, "out", (torch.uint8, torch.float8_e4m3fn))
+        if fp8_scale.dtype != f32 or not fp8_scale.is_contiguous() or fp8_scale.numel() < out.shape[0]:
+            raise ValueError("fp8_scale must be contiguous f32 with one entry per output row")
+    else:
+        _chk2d(out, "out", (bf16, f32))
     mstride = 0
     if scale is not None:
         if scale.dtype != f32 or shift is None or shift.dtype != f32 or scale.dim() != 2 or shift.dim() != 2:
@@ -384,7 +391,7 @@ def layernorm(
     args = L.LayerNormArgs(
         _ptr(x), _ptr(out), _ptr(weight), _ptr(bias), _ptr(scale), _ptr(shift),
         M, d, x.stride(0), out.stride(0), rows_per_batch, mstride, eps,
-        int(x.dtype == f32), int(out.dtype == f32), *in_rows, *out_rows, int(rms),
+        int(x.dtype == f32), int(out.dtype == f32), *in_rows, *out_rows, int(rms), _ptr(fp8_scale),
     )
     L.check(L.load().v3a_layernorm(C.byref(args), _stream()), "v3a_layernorm")
     return out

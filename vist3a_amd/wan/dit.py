@@ -311,11 +311,18 @@ class WanDiT:
             return ops.gemm(a8, b[w + "8"], bias, a_scale=sa, w_scale=b["s" + w], **kw)
         lin.last = None
 
+        def norm(**kw):
+            """ws.n = LN(x) (bf16), or in the fp8 mode its per-token e4m3 image straight from the LayerNorm kernel"""
+            if g8:
+                ops.layernorm(x, out=ws.a8, fp8_scale=ws.sa, eps=cfg.eps, **kw)
+                lin.last = ws.n
+            else:
+                ops.layernorm(x, out=ws.n, eps=cfg.eps, **kw)
+
         for li in range(nl):
             b, m = self.blocks[li], mod[li]
             # --- self attention
-            ops.layernorm(x, out=ws.n, scale=m[:, 1], shift=m[:, 0], rows_per_batch=Nl, eps=cfg.eps)
-            lin.last = None
+            norm(scale=m[:, 1], shift=m[:, 0], rows_per_batch=Nl)
             if P == 1:
                 lin(ws.n, b, "wqk", b["bqk"], out=ws.qk)
                 if g8:   # V^T = Wv . X^T: the weight rows are the GEMM's A side
@@ -365,8 +372,7 @@ class WanDiT:
             lin.last = None
             lin(ws.ao, b, "wo", b["bo"], out=x, residual=x, scale=m[:, 2], rows_per_batch=Nl)
             # --- cross attention
-            ops.layernorm(x, out=ws.n, weight=b["n2w"], bias=b["n2b"], eps=cfg.eps)
-            lin.last = None
+            norm(weight=b["n2w"], bias=b["n2b"])
             lin(ws.n, b, "wq2", b["bq2"], out=ws.q2)
             ops.rmsnorm_rope(ws.q2, b["nq2"], out=ws.q2, eps=cfg.eps)
             ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lk, D=hd, q_batch_stride=Nl * d,
@@ -375,8 +381,7 @@ class WanDiT:
             lin.last = None
             lin(ws.ao, b, "wo2", b["bo2"], out=x, residual=x)
             # --- feed forward
-            ops.layernorm(x, out=ws.n, scale=m[:, 4], shift=m[:, 3], rows_per_batch=Nl, eps=cfg.eps)
-            lin.last = None
+            norm(scale=m[:, 4], shift=m[:, 3], rows_per_batch=Nl)
             lin(ws.n, b, "w1", b["b1"], out=ws.h, act=L.ACT_GELU_TANH)
             lin(ws.h, b, "w2", b["b2"], out=x, residual=x, scale=m[:, 5], rows_per_batch=Nl)
 
