@@ -15,15 +15,18 @@ for b in range(B):
     vt[:, b * N:(b + 1) * N] = v[b * N:(b + 1) * N].t()
 o = torch.empty(B * N, d, device="cuda", dtype=torch.bfloat16)
 run = lambda: ops.attention(q, k, vt, o, B=B, H=H, Nq=N, Nk=N, D=D, q_batch_stride=N * d, k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=N * d)
-for _ in range(3): run()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
 for _ in range(20): run()
-e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / 20 * 1e3
+torch.cuda.synchronize()
+times = []
+for _ in range(6):   # the first rounds run on cold clocks: report all, quote the best
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50): run()
+    e1.record(); torch.cuda.synchronize()
+    times.append(round(e0.elapsed_time(e1) / 50 * 1e3, 1))
+us = min(times)
 # reference on one (b, h)
 qf, kf, vf = q[:N, :D].float(), k[:N, :D].float(), v[:N, :D].float()
 ref = torch.softmax(qf @ kf.t() * D ** -0.5, -1) @ vf
 rel = ((o[:N, :D].float() - ref).norm() / ref.norm()).item()
-print(json.dumps(dict(mode="occ3" if os.environ.get("V3A_ATTN3") else "occ2", us=round(us, 1), tflops=round(4 * B * H * N * N * D / us / 1e6), rel=rel)))
+print(json.dumps(dict(mode="occ2" if os.environ.get("V3A_ATTN_OCC2") else "occ3", us=round(us, 1), rounds_us=times, tflops=round(4 * B * H * N * N * D / us / 1e6), rel=rel)))

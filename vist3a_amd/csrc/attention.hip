@@ -13,10 +13,9 @@
 //          produced directly by the projection GEMM in its V^T = Wv.X^T form, zero padded to a
 //          multiple of 64 keys.
 //   O    : [batch][token][head*D + d]
-// Two schedules of the same arithmetic: `attn_fwd_kernel` (K and V^T double-buffered, 64 KB, two workgroups per CU; used for
-// hd = 64 and the relative-bias variant) and `attn_fwd_kernel3` (hd = 128: K double-, V^T single-buffered, 48 KB, THREE
-// workgroups per CU — the DiT's 98304 query rows are exactly 12 waves per CU, so 3 x 4 waves is one full round where 2 x 4
-// leaves a half-empty second one: 706 -> 807 TFLOP/s on the self-attention launch, bit-identical output).
+// One kernel template, two staging schedules of the same arithmetic (template flag V1, see attn_fwd_kernel): K and V^T
+// double-buffered with two workgroups per CU (hd = 64, relative-bias variant), or V^T single-buffered with THREE workgroups per CU
+// (hd = 128: 706 -> 807 TFLOP/s on the DiT self-attention launch, bit-identical output).
 // Per workgroup: NW waves x 32 queries.  Per 64-key tile each wave computes
 //   S^T[key][q]  = K_tile . Q^T        (A = K rows from LDS, B = Q fragments held in registers)
 //   O^T[d][q]   += V^T_tile . P^T      (A = V^T rows from LDS, B = P straight from the S^T registers)
@@ -48,250 +47,14 @@ struct AttnP {
   long k_seg, vt_seg;             //      key kk of a batch item is row (kk % kv_seg) of segment kk / kv_seg, segments k_seg / vt_seg elements apart
 };
 
-template <int D, int NW, bool RELB>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const AttnP p) {
-  constexpr int KV = 64;                 // keys per tile
-  constexpr int KROWB = D * 2;           // bytes per K row in LDS
-  constexpr int KCPR = KROWB / 16;       // 16-B chunks per K row (16 or 8)
-  constexpr int KRPI = 64 / KCPR;        // K rows per DMA instruction (4 or 8)
-  constexpr int KTILE = KV * KROWB;      // bytes
-  constexpr int VTILE = D * 128;         // D rows x 64 keys x 2 B
-  constexpr int STAGE = KTILE + VTILE;
-  constexpr int KINS = KTILE / 1024 / NW;  // DMA instructions per wave per tile (K)
-  constexpr int VINS = VTILE / 1024 / NW;
-  constexpr int KS = D / 16;             // k-steps of QK^T
-  constexpr int DT = D / 32;             // 32-row d tiles of O^T
-  constexpr int OPITCH = D * 2 + 8;
-  static_assert(KTILE % (1024 * NW) == 0 && VTILE % (1024 * NW) == 0, "tile/wave split");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  // block -> (batch, head, query block); consecutive blocks of one (batch, head) share K/V in L2:
-  // hardware places block b on XCD b%8, so make the q-block index vary slowest across XCD lanes.
-  const int nqb = (p.Nq + NW * 32 - 1) / (NW * 32);
-  const int nbh = gridDim.x / nqb;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = bid / nqb, qb = bid % nqb;
-  (void)nbh;
-  const int b = bh / p.H, h = bh % p.H;
-  const int q0 = qb * (NW * 32) + wave * 32;
-
-  const char* Qb = p.q + ((size_t)b * p.q_bs + (size_t)h * D) * 2;
-  const char* Kb = p.k + ((size_t)b * p.k_bs + (size_t)h * D) * 2;
-  const char* Vb = p.vt + ((size_t)h * D * p.ldvt + (size_t)b * p.vt_bs) * 2;
-
-  // ---- Q fragments (B operand): lane (q = l31, hi) slot j <-> d = 16*ks + 8*hi + j ----
-  bf16x8 qf[KS];
-  {
-    int qr = q0 + l31;
-    qr = qr < p.Nq ? qr : p.Nq - 1;
-    const char* qp = Qb + (size_t)qr * p.ldq * 2 + hi * 16;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
-  }
-
-  // ---- DMA sources ----
-  const char* kp[KINS];
-  const char* vp[VINS];
-  int krow[KINS];
-#pragma unroll
-  for (int j = 0; j < KINS; ++j) {
-    const int g = j * NW + wave;
-    const int r = g * KRPI + lane / KCPR;
-    const int c = lane % KCPR;
-    const int f = (KCPR == 16) ? (r & 15) : ((r >> 1) & 7);
-    krow[j] = r;
-    kp[j] = Kb + (size_t)(c ^ f) * 16;  // + row*ldk*2 added per tile (row clamp depends on tile)
-  }
-#pragma unroll
-  for (int j = 0; j < VINS; ++j) {
-    const int g = j * NW + wave;
-    const int r = g * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    vp[j] = Vb + ((size_t)r * p.ldvt + c * 8) * 2;
-  }
-  auto stage = [&](int s, int kt) {
-    char* sb = smem + s * STAGE;
-#pragma unroll
-    for (int j = 0; j < KINS; ++j) {
-      int row = kt * KV + krow[j];
-      row = row < p.Nk ? row : p.Nk - 1;
-      glds16(kp[j] + (size_t)row * p.ldk * 2, sb + (j * NW + wave) * 1024);
-    }
-#pragma unroll
-    for (int j = 0; j < VINS; ++j) glds16(vp[j] + (size_t)kt * KV * 2, sb + KTILE + (j * NW + wave) * 1024);
-  };
-
-  // ---- fragment read offsets ----
-  // K (A operand of QK^T): MFMA row i = l31 <-> key pi(i) inside the 32-key sub-tile
-  const int pi = (l31 & 3) + 4 * (l31 >> 3) + 16 * ((l31 >> 2) & 1);
-  int kfo[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int cc = 2 * ks + hi;
-    const int f = (KCPR == 16) ? (pi & 15) : ((pi >> 1) & 7);  // (pi+32)&15 == pi&15, ((pi+32)>>1)&7 == (pi>>1)&7
-    kfo[ks] = pi * KROWB + ((cc ^ f) << 4);
-  }
-  // V^T (A operand of PV): row d = l31 (+32*dt), chunk = 4*t32 + 2*hi + ks2
-  int vfo[4];
-#pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) {
-    const int t32 = c4 >> 1, ks2 = c4 & 1;
-    const int cc = 4 * t32 + 2 * hi + ks2;
-    vfo[c4] = l31 * 128 + ((cc ^ ((l31 >> 1) & 7)) << 4);
-  }
-
-  f32x16 oacc[DT];
-#pragma unroll
-  for (int i = 0; i < DT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const float c = p.scale_log2e;
-
-  const int nkt = (p.Nk + KV - 1) / KV;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-    const char* sK = smem + cur * STAGE;
-    const char* sV = sK + KTILE;
-
-    // S^T = K . Q^T  (two 32-key sub-tiles)
-    f32x16 s[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(sK + t * 32 * KROWB + kfo[ks]);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
-      }
-    }
-    // lane (q = l31, hi) now holds keys kt*64 + 32*t + 16*hi + r, r = 0..15
-    if constexpr (RELB) {  // T5-style relative position bias (UMT5 text encoder): 16 consecutive table entries per sub-tile
-      const float* tb = p.relb + (size_t)h * p.relb_stride + p.relb_center + (kt * KV + 16 * hi) - min(q0 + l31, p.Nq - 1);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * KV + 32 * t + 16 * hi + r;
-          if (key < p.Nk) s[t][r] += tb[32 * t + r] * p.inv_scale;
-        }
-    }
-    if (kt == nkt - 1 && (p.Nk & (KV - 1))) {
-      const int kb = kt * KV + 16 * hi;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kb + 32 * t + r >= p.Nk) s[t][r] = -1e30f;
-    }
-    if (p.kv_period > 0) {  // padded multi-frame token layout: mask the per-frame filler rows
-      const int pos = (kt * KV) % p.kv_period;
-      if (pos + KV > p.kv_valid) {  // some key of this tile is filler (always true for periods < 64)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = (pos + 32 * t + 16 * hi + r) % p.kv_period;
-            if (o >= p.kv_valid) s[t][r] = -1e30f;
-          }
-      }
-    }
-    float mx = s[0][0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
-    float psum = 0.f;
-    bf16x8 pf[4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float pv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(s[t][r] * c - mc);
-        psum += pv[r];
-      }
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-        u32x4 pk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(pv[8 * ks2 + 2 * e], pv[8 * ks2 + 2 * e + 1]);
-        pf[2 * t + ks2] = __builtin_bit_cast(bf16x8, pk);
-      }
-    }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < DT; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-    // O^T += V^T . P^T
-#pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) {
-#pragma unroll
-      for (int i = 0; i < DT; ++i) {
-        const bf16x8 vf = *(const bf16x8*)(sV + i * 4096 + vfo[c4]);
-        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c4], oacc[i], 0, 0, 0);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // reads retired too: the compiler may sink the last MFMA below
-    __builtin_amdgcn_s_barrier();
-  }
-
-  // ---- finish: combine the two key halves of l, normalise, park O as [q][d] in LDS, store rows ----
-  l_run += __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_run;
-  char* reg = smem + wave * (32 * OPITCH);
-#pragma unroll
-  for (int i = 0; i < DT; ++i) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int d = i * 32 + g * 8 + hi * 4;
-      u32x2 pk;
-      pk[0] = pack_bf16x2(oacc[i][g * 4 + 0] * inv, oacc[i][g * 4 + 1] * inv);
-      pk[1] = pack_bf16x2(oacc[i][g * 4 + 2] * inv, oacc[i][g * 4 + 3] * inv);
-      *(u32x2*)(reg + l31 * OPITCH + d * 2) = pk;
-    }
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  constexpr int CH = D / 8;  // 16-B chunks per output row
-  char* Ob = p.o + ((size_t)b * p.o_bs + (size_t)h * D) * 2;
-#pragma unroll
-  for (int it = 0; it < 32 * CH / 64; ++it) {
-    const int idx = it * 64 + lane;
-    const int ql = idx / CH, ch = idx % CH;
-    const u32x2 lo = *(const u32x2*)(reg + ql * OPITCH + ch * 16);
-    const u32x2 hi2 = *(const u32x2*)(reg + ql * OPITCH + ch * 16 + 8);
-    const int qr = q0 + ql;
-    if (qr < p.Nq) {
-      u32x4 v;
-      v[0] = lo[0]; v[1] = lo[1]; v[2] = hi2[0]; v[3] = hi2[1];
-      *(u32x4*)(Ob + ((size_t)qr * p.ldo) * 2 + ch * 16) = v;
-    }
-  }
-}
-
-// Variant with THREE workgroups per CU (98304 query rows = 12 waves of 32 per CU: 3 x 4 waves is one exact round where
-// 2 x 4 leaves a half-filled second round).  LDS per workgroup 48 KB: K double-buffered, V^T single-buffered and fetched
-// while S = K.Q^T and the softmax run; two barriers per tile, hidden by the other two workgroups.
-template <int D, int NW, bool KBIAS>
-__global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
-  constexpr bool RELB = false;
+// One source, two staging schedules of the same arithmetic (V1):
+//   V1 = false: K and V^T tiles double-buffered (64 KB at hd = 128), two workgroups per CU - hd = 64 and the relative-bias variant;
+//   V1 = true : K double-, V^T SINGLE-buffered (48 KB) and fetched under S and the softmax of its own tile, THREE workgroups per CU -
+//               the DiT's 98304 query rows are exactly 12 waves of 32 per CU (3 x 4 waves is one full round where 2 x 4 leaves a
+//               half-empty second one); one extra barrier per tile orders the V^T landing before the PV MFMAs.
+template <int D, int NW, bool RELB, bool KBIAS, bool V1>
+__global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const AttnP p) {
+  constexpr int KSTRIDE = V1 ? 64 * D * 2 : 64 * D * 2 + D * 128;   // distance between the two K buffers
   constexpr int KV = 64;                 // keys per tile
   constexpr int KROWB = D * 2;           // bytes per K row in LDS
   constexpr int KCPR = KROWB / 16;       // 16-B chunks per K row (16 or 8)
@@ -358,7 +121,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
   // with kv_seg (sequence-parallel: K / V^T are read straight from the all-gathered per-rank slabs, no reassembly copy) a 64-key
   // tile lies inside one segment: its wave-uniform base moves by (k_seg - kv_seg * ldk) / (vt_seg - kv_seg) per segment crossed
   auto stage_k = [&](int s, int kt) {
-    char* sb = smem + s * KTILE;
+    char* sb = smem + s * KSTRIDE;
     const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.k_seg - (long)p.kv_seg * p.ldk) * 2 : 0;
 #pragma unroll
     for (int j = 0; j < KINS; ++j) {
@@ -367,10 +130,11 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
       glds16(kp[j] + (size_t)row * p.ldk * 2 + so, sb + (j * NW + wave) * 1024);
     }
   };
-  auto stage_v = [&](int kt) {
+  auto stage_v = [&](int s, int kt) {
+    char* sv = V1 ? smem + 2 * KTILE : smem + s * KSTRIDE + KTILE;
     const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.vt_seg - p.kv_seg) * 2 : 0;
 #pragma unroll
-    for (int j = 0; j < VINS; ++j) glds16(vp[j] + (size_t)kt * KV * 2 + so, smem + 2 * KTILE + (j * NW + wave) * 1024);
+    for (int j = 0; j < VINS; ++j) glds16(vp[j] + (size_t)kt * KV * 2 + so, sv + (j * NW + wave) * 1024);
   };
 
   // ---- fragment read offsets ----
@@ -402,15 +166,21 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
 
   const int nkt = (p.Nk + KV - 1) / KV;
   stage_k(0, 0);
+  if constexpr (!V1) stage_v(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
-    stage_v(kt);                                  // V^T of this tile: lands under S and the softmax
-    if (kt + 1 < nkt) stage_k(cur ^ 1, kt + 1);   // K of the next tile
-    const char* sK = smem + cur * KTILE;
-    const char* sV = smem + 2 * KTILE;
+    if constexpr (V1) {
+      stage_v(0, kt);                               // V^T of this tile: lands under S and the softmax
+      if (kt + 1 < nkt) stage_k(cur ^ 1, kt + 1);   // K of the next tile
+    } else if (kt + 1 < nkt) {
+      stage_k(cur ^ 1, kt + 1);
+      stage_v(cur ^ 1, kt + 1);
+    }
+    const char* sK = smem + cur * KSTRIDE;
+    const char* sV = V1 ? smem + 2 * KTILE : sK + KTILE;
 
     // S^T = K . Q^T  (two 32-key sub-tiles)
     f32x16 s[2];
@@ -501,10 +271,12 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
     }
-    // V^T pieces were issued before the K pieces: leave the K prefetch in flight
-    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave's V^T pieces have landed
+    if constexpr (V1) {
+      // V^T pieces were issued before the K pieces: leave the K prefetch in flight
+      if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's V^T pieces have landed
+    }
     // O^T += V^T . P^T
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
@@ -555,30 +327,14 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_kernel3(const AttnP p) {
   }
 }
 
-template <int D, int NW, bool RELB>
+template <int D, int NW, bool RELB, bool KBIAS, bool V1>
 int launch_attn(const AttnP& p, int B, void* stream) {
-  constexpr int STAGE = 64 * D * 2 + D * 128;
-  constexpr int OBYTES = NW * 32 * (D * 2 + 8);
-  constexpr int LDS = (2 * STAGE > OBYTES) ? 2 * STAGE : OBYTES;
-  static bool attr = false;
-  auto fn = attn_fwd_kernel<D, NW, RELB>;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-      return V3A_ERR_LAUNCH;
-    attr = true;
-  }
-  const int nqb = (p.Nq + NW * 32 - 1) / (NW * 32);
-  hipLaunchKernelGGL(fn, dim3((unsigned)(nqb * B * p.H)), dim3(NW * 64), LDS, (hipStream_t)stream, p);
-  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
-}
-
-template <int D, int NW, bool KBIAS>
-int launch_attn3(const AttnP& p, int B, void* stream) {
   constexpr int KT = 64 * D * 2, VT = D * 128;
+  constexpr int RING = V1 ? 2 * KT + VT : 2 * (KT + VT);
   constexpr int OBYTES = NW * 32 * (D * 2 + 8);
-  constexpr int LDS = (2 * KT + VT > OBYTES) ? 2 * KT + VT : OBYTES;
+  constexpr int LDS = RING > OBYTES ? RING : OBYTES;
   static bool attr = false;
-  auto fn = attn_fwd_kernel3<D, NW, KBIAS>;
+  auto fn = attn_fwd_kernel<D, NW, RELB, KBIAS, V1>;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return V3A_ERR_LAUNCH;
@@ -613,7 +369,7 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   p.inv_scale = 1.0f / a->scale;
   if (a->rel_bias) {  // needs table entries for every (key - query) in [-(Nq-1), Nk-1]
     if (a->D != 64 || a->rel_bias_center < a->Nq - 1 || a->rel_bias_stride < a->rel_bias_center + a->Nk) return V3A_ERR_SHAPE;
-    return launch_attn<64, 4, true>(p, a->B, stream);
+    return launch_attn<64, 4, true, false, false>(p, a->B, stream);
   }
   static const bool two_per_cu = getenv("V3A_ATTN_OCC2") != nullptr;  // A/B switch for the older 2-workgroup schedule
   p.kbias = a->key_bias; p.kbias_stride = a->key_bias_stride; p.kbias_first = a->key_bias_first > 0 ? a->key_bias_first : 0;
@@ -622,8 +378,8 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
                                          a->k_seg_stride % 8 || a->vt_seg_stride % 8))) return V3A_ERR_SHAPE;
   if (a->key_bias) {
     if (a->D != 128 || a->rel_bias || a->key_bias_stride < a->Nk) return V3A_ERR_SHAPE;
-    return launch_attn3<128, 4, true>(p, a->B, stream);
+    return launch_attn<128, 4, false, true, true>(p, a->B, stream);
   }
-  if (a->D == 128) return (two_per_cu && !a->kv_seg) ? launch_attn<128, 4, false>(p, a->B, stream) : launch_attn3<128, 4, false>(p, a->B, stream);
-  return launch_attn<64, 4, false>(p, a->B, stream);  // recon (hd = 64): the 3-per-CU schedule measured no gain there
+  if (a->D == 128) return two_per_cu ? launch_attn<128, 4, false, false, false>(p, a->B, stream) : launch_attn<128, 4, false, false, true>(p, a->B, stream);
+  return launch_attn<64, 4, false, false, false>(p, a->B, stream);  // recon (hd = 64): the 3-per-CU schedule measured no gain there
 }
