@@ -240,10 +240,19 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // Deferred rescale: m_run is the REFERENCE of the exponentials, not necessarily the running maximum.  It moves (and l / O are
+    // rescaled) only when some lane's maximum outgrew it by more than 2^DEFER; until then p = 2^((s - m_run) c) <= 2^DEFER, which
+    // costs bf16 no precision, and the 64 accumulator multiplies per tile are skipped (on random scores: every tile but the first
+    // few).  O / l at the end is invariant to the reference.
+    constexpr float DEFER = 8.0f;
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
+    const bool rescale = __builtin_amdgcn_ballot_w64((m_new - m_run) * c > DEFER) != 0;
+    float alpha = 1.0f;
+    if (rescale) {
+      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+    }
+    const float mc = m_run * c;
     float psum = 0.f;
     bf16x8 pf[4];
 #pragma unroll
@@ -263,9 +272,7 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
       }
     }
     l_run = l_run * alpha + psum;
-    // the running maximum settles after the first few tiles: skip the 64 accumulator multiplies while no lane's maximum moved
-    // (alpha == 1 exactly then, so the result is bit-identical to always rescaling)
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+    if (rescale) {
 #pragma unroll
       for (int i = 0; i < DT; ++i)
 #pragma unroll
