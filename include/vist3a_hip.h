@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 10) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 11) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -151,8 +151,14 @@ typedef struct {
                              * slabs of sequence-parallel attention are read in place.  Inside a segment: ldk / k_batch_stride / ldvt /
                              * vt_batch_stride as usual */
   long k_seg_stride, vt_seg_stride;
+  int kv_split;             /* optional (D = 128 only): > 1 divides the key tiles of every query block among kv_split workgroups and
+                             * merges their partial softmaxes in a second launch (fixed order: deterministic, but not bit-identical to
+                             * kv_split <= 1).  For launches too small to occupy the chip: a sequence-parallel shard has N / P query rows
+                             * but walks all N keys per workgroup. */
+  void* workspace;          /* kv_split > 1: v3a_attention_split_workspace_bytes(B, H, Nq, D, kv_split) bytes */
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
+size_t v3a_attention_split_workspace_bytes(int B, int H, int Nq, int D, int kv_split);
 
 /* ------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) flash attention forward on the block-scaled MFMA (K = 64, twice the bf16 rate): the self-attention launch of

@@ -400,18 +400,25 @@ def test_seq_parallel_production_width_reads_gathered_slabs_in_place(hip_lib, P)
     lat = torch.randn(1, 16, 4, 64, 64, generator=g).bfloat16().cuda()
     t = torch.tensor([700]).cuda()
     full = m(lat, t, text)[0].clone()
-    seen = []
+    seen, splits = [], []
     real = ops.attention
     def spy(*a, **kw):
         seen.append(kw.get("kv_seg", 0))
+        splits.append(kw.get("kv_split", 1))
         return real(*a, **kw)
     ops.attention = spy
     try:
         w = ThreadWorld(P)
+        m.sp_kv_split = 1     # every workgroup walks all keys in the unsharded order: bit-identical
         outs = w.run(lambda r: m(lat, t, text, sp=w.group(r))[0].clone())
+        m.sp_kv_split = None  # default: the keys of a query block divided among workgroups so that the small launch fills the chip
+        outs_split = w.run(lambda r: m(lat, t, text, sp=w.group(r))[0].clone())
         torch.cuda.synchronize()
     finally:
         ops.attention = real
     assert 4096 // P in seen, "self-attention did not take the in-place slab path"
+    assert max(splits) > 1, "the default sequence-parallel path did not split the keys"
     for o in outs:
         assert torch.equal(o, full)
+    for o in outs_split:
+        assert torch.equal(o, outs_split[0]) and _rel(o, full) < 5e-3, _rel(o, full)   # bf16 rounding of the merged softmax

@@ -199,6 +199,24 @@ def test_attention_hd128_dit_self_attention_shape(hip_lib, parity):
     assert r < 5e-3, r
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,S", [(1, 12, 1024, 4096, 8), (2, 12, 512, 4096, 5), (1, 40, 1000, 4096 + 37, 3), (2, 3, 130, 200, 4)])
+def test_attention_key_split_matches_unsplit_and_fp32(hip_lib, parity, B, H, Nq, Nk, S):
+    """kv_split (sequence-parallel shards: few query rows against all keys): partial softmaxes over S key ranges merged by the second
+    launch - against fp32 attention and against the unsplit kernel (bf16 rounding of the output apart), run to run deterministic,
+    ragged key counts and a split count that does not divide the tile count included."""
+    D = 128
+    g = torch.Generator(device=dev).manual_seed(Nq + S)
+    q, k, v, vt, nkp = _attn_inputs(B, H, Nq, Nk, D, g)
+    one = _run_attn(q, k, vt, nkp, B, H, Nq, Nk, D)
+    a = _run_attn(q, k, vt, nkp, B, H, Nq, Nk, D, kv_split=S)
+    b = _run_attn(q, k, vt, nkp, B, H, Nq, Nk, D, kv_split=S)
+    ref = _attn_ref(q, k, v, B, H, D)
+    r, r1 = relerr(a, ref), relerr(a, one)
+    parity("attention_hd128_key_split", B=B, H=H, Nq=Nq, Nk=Nk, S=S, rel_vs_fp32=r, rel_vs_unsplit=r1)
+    assert torch.equal(a, b)
+    assert r < 5e-3 and r1 < 6e-3, (r, r1)   # two bf16-P flash results differ by ~sqrt(2) x their own 2.3e-3
+
+
 def test_attention_hd128_cross_attention_merged_padding_keys(hip_lib, parity):
     """Cross-attention as run in production: 88 keys (87 real + one merged padding key carrying log(count) as key bias)."""
     B, H, Nq, Nk, D = 2, 12, 4096, 88, 128

@@ -45,6 +45,8 @@ struct AttnP {
   int kbias_stride, kbias_first;  // keys below kbias_first have zero bias: tiles entirely below it skip the loads
   int kv_seg;                     // > 0: keys live in segments of kv_seg (a multiple of 64) keys, one per all-gathered rank slab:
   long k_seg, vt_seg;             //      key kk of a batch item is row (kk % kv_seg) of segment kk / kv_seg, segments k_seg / vt_seg elements apart
+  int kv_split, B;                // > 1: the key tiles are divided among kv_split workgroups per query block, each writing an
+  float* ws_o; float* ws_ml;      //      UNNORMALISED fp32 partial O [S][B][Nq][H*D] and its (reference, sum) [S][B][Nq][H][2]
 };
 
 // One source, two staging schedules of the same arithmetic (V1):
@@ -76,11 +78,11 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
 
   // block -> (batch, head, query block); consecutive blocks of one (batch, head) share K/V in L2:
   // hardware places block b on XCD b%8, so make the q-block index vary slowest across XCD lanes.
+  const int S = p.kv_split > 1 ? p.kv_split : 1;
   const int nqb = (p.Nq + NW * 32 - 1) / (NW * 32);
-  const int nbh = gridDim.x / nqb;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid0 % S, bid = bid0 / S;
   const int bh = bid / nqb, qb = bid % nqb;
-  (void)nbh;
   const int b = bh / p.H, h = bh % p.H;
   const int q0 = qb * (NW * 32) + wave * 32;
 
@@ -165,17 +167,18 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
   const float c = p.scale_log2e;
 
   const int nkt = (p.Nk + KV - 1) / KV;
-  stage_k(0, 0);
-  if constexpr (!V1) stage_v(0, 0);
+  const int kt0 = (int)((long)split * nkt / S), kt1 = (int)((long)(split + 1) * nkt / S);   // this workgroup's key tiles
+  stage_k(0, kt0);
+  if constexpr (!V1) stage_v(0, kt0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
     if constexpr (V1) {
       stage_v(0, kt);                               // V^T of this tile: lands under S and the softmax
-      if (kt + 1 < nkt) stage_k(cur ^ 1, kt + 1);   // K of the next tile
-    } else if (kt + 1 < nkt) {
+      if (kt + 1 < kt1) stage_k(cur ^ 1, kt + 1);   // K of the next tile
+    } else if (kt + 1 < kt1) {
       stage_k(cur ^ 1, kt + 1);
       stage_v(cur ^ 1, kt + 1);
     }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
     }
     if constexpr (V1) {
       // V^T pieces were issued before the K pieces: leave the K prefetch in flight
-      if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
+      if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave's V^T pieces have landed
     }
@@ -302,6 +305,27 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
 
   // ---- finish: combine the two key halves of l, normalise, park O as [q][d] in LDS, store rows ----
   l_run += __shfl_xor(l_run, 32, 64);
+  if (S > 1) {   // split keys: unnormalised partial O (fp32) + its reference and sum; attn_combine_kernel finishes the softmax
+    const int qr = q0 + l31;
+    if (qr < p.Nq) {
+      const size_t row = ((size_t)split * p.B + b) * p.Nq + qr;
+      float* po = p.ws_o + (row * p.H + h) * D;
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = oacc[i][g * 4 + e];
+          *(f32x4*)(po + i * 32 + g * 8 + hi * 4) = v;
+        }
+      if (hi == 0) {
+        float* pm = p.ws_ml + (row * p.H + h) * 2;
+        pm[0] = m_run; pm[1] = l_run;
+      }
+    }
+    return;
+  }
   const float inv = 1.0f / l_run;
   char* reg = smem + wave * (32 * OPITCH);
 #pragma unroll
@@ -334,6 +358,39 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
   }
 }
 
+// Finish a key-split attention: one wave per (batch, query, head) merges the S partial softmaxes,
+//   O = sum_s 2^((m_s - M) c) O_s / sum_s 2^((m_s - M) c) l_s,   M = max_s m_s,
+// in a fixed order (deterministic), and writes the bf16 row.
+template <int D>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const AttnP p) {
+  const int lane = threadIdx.x & 63;
+  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, q, h)
+  const long total = (long)p.B * p.Nq * p.H;
+  if (idx >= total) return;
+  const int h = (int)(idx % p.H);
+  const long bq = idx / p.H;
+  const int q = (int)(bq % p.Nq), b = (int)(bq / p.Nq);
+  const int S = p.kv_split;
+  const long sstride = (long)p.B * p.Nq * p.H;   // (b, q, h) entries per split
+  float M = -3.0e38f;
+  for (int s = 0; s < S; ++s) M = fmaxf(M, p.ws_ml[(s * sstride + idx) * 2]);
+  constexpr int E = D / 64;
+  float acc[E] = {};
+  float L = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float* ml = p.ws_ml + (s * sstride + idx) * 2;
+    const float w = __builtin_amdgcn_exp2f((ml[0] - M) * p.scale_log2e);
+    L += w * ml[1];
+    const float* po = p.ws_o + (s * sstride + idx) * D + lane * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] += w * po[e];
+  }
+  const float inv = 1.0f / L;
+  char* o = p.o + ((size_t)b * p.o_bs + (size_t)q * p.ldo + (size_t)h * D + lane * E) * 2;
+  if constexpr (E == 2) *(unsigned*)o = pack_bf16x2(acc[0] * inv, acc[1] * inv);
+  else *(unsigned short*)o = (unsigned short)(pack_bf16x2(acc[0] * inv, 0.f) & 0xffffu);
+}
+
 template <int D, int NW, bool RELB, bool KBIAS, bool V1>
 int launch_attn(const AttnP& p, int B, void* stream) {
   constexpr int KT = 64 * D * 2, VT = D * 128;
@@ -348,11 +405,21 @@ int launch_attn(const AttnP& p, int B, void* stream) {
     attr = true;
   }
   const int nqb = (p.Nq + NW * 32 - 1) / (NW * 32);
-  hipLaunchKernelGGL(fn, dim3((unsigned)(nqb * B * p.H)), dim3(NW * 64), LDS, (hipStream_t)stream, p);
+  const int S = p.kv_split > 1 ? p.kv_split : 1;
+  hipLaunchKernelGGL(fn, dim3((unsigned)(nqb * B * p.H * S)), dim3(NW * 64), LDS, (hipStream_t)stream, p);
+  if (S > 1) {
+    const long waves = (long)B * p.Nq * p.H;
+    hipLaunchKernelGGL(attn_combine_kernel<D>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  }
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
 }  // namespace
+
+extern "C" size_t v3a_attention_split_workspace_bytes(int B, int H, int Nq, int D, int kv_split) {
+  if (B <= 0 || H <= 0 || Nq <= 0 || D <= 0 || kv_split <= 1) return 0;
+  return (size_t)kv_split * B * Nq * H * (D + 2) * sizeof(float);
+}
 
 extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   if (!a || !a->q || !a->k || !a->vt || !a->o) return V3A_ERR_ARG;
@@ -383,10 +450,24 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   p.kv_seg = a->kv_seg; p.k_seg = a->k_seg_stride; p.vt_seg = a->vt_seg_stride;
   if (a->kv_seg < 0 || (a->kv_seg > 0 && (a->kv_seg % 64 || a->Nk % a->kv_seg || a->D != 128 || a->rel_bias || a->key_bias ||
                                          a->k_seg_stride % 8 || a->vt_seg_stride % 8))) return V3A_ERR_SHAPE;
+  p.B = a->B; p.kv_split = a->kv_split > 1 ? a->kv_split : 1; p.ws_o = nullptr; p.ws_ml = nullptr;
+  if (a->kv_split < 0) return V3A_ERR_ARG;
+  if (p.kv_split > 1) {   // workspace = [S][B][Nq][H][D] fp32 partial O, then [S][B][Nq][H][2] (reference, sum)
+    if (a->D != 128 || a->rel_bias || !a->workspace || p.kv_split > (a->Nk + 63) / 64) return V3A_ERR_ARG;
+    p.ws_o = (float*)a->workspace;
+    p.ws_ml = p.ws_o + (size_t)p.kv_split * a->B * a->Nq * a->H * a->D;
+  }
   if (a->key_bias) {
     if (a->D != 128 || a->rel_bias || a->key_bias_stride < a->Nk) return V3A_ERR_SHAPE;
     return launch_attn<128, 4, false, true, true>(p, a->B, stream);
   }
-  if (a->D == 128) return two_per_cu ? launch_attn<128, 4, false, false, false>(p, a->B, stream) : launch_attn<128, 4, false, false, true>(p, a->B, stream);
+  if (a->D == 128) {
+    if (two_per_cu) return launch_attn<128, 4, false, false, false>(p, a->B, stream);
+    // a sequence-parallel shard (Nq = N / P queries against all N keys) has too few 128-query blocks to occupy 256 CUs: 64-query
+    // workgroups double the count; per-wave arithmetic and key order are unchanged, so the output stays bit-identical
+    const long wgs4 = (long)a->B * a->H * ((a->Nq + 127) / 128) * p.kv_split;
+    if (wgs4 < 256) return launch_attn<128, 2, false, false, true>(p, a->B, stream);
+    return launch_attn<128, 4, false, false, true>(p, a->B, stream);
+  }
   return launch_attn<64, 4, false, false, false>(p, a->B, stream);  // recon (hd = 64): the 3-per-CU schedule measured no gain there
 }

@@ -950,6 +950,10 @@ const TileEntry kTiles[] = {
     PP_ENTRY(3, true, 5),    // 6: 256x192 (d = 1536 = 8 x 192: 8192x1536 -> exactly 256 tiles)
     PP_ENTRY(4, true, 7),    // 7: 256x256
     PP_ENTRY(3, false, 5),   // 8: 192x256 (V^T = Wv . X^T)
+    // small tiles for problems that cannot fill 256 CUs with the big ones (sequence-parallel shards: M = N_tokens / P rows)
+    TILE_ENTRY(64, 128, 2, 2, 64, 2),   // 9
+    TILE_ENTRY(128, 64, 2, 2, 64, 2),   // 10
+    TILE_ENTRY(64, 64, 2, 2, 64, 2),    // 11
 #ifdef V3A_GEMM_ABL
     PP_ABL(4, true, 7, 1), PP_ABL(4, true, 7, 2), PP_ABL(4, true, 7, 3), PP_ABL(4, true, 7, 4), PP_ABL(4, true, 7, 5), PP_ABL(4, true, 7, 6),
     PP_ABL(3, true, 5, 1), PP_ABL(3, true, 5, 3), PP_ABL(3, true, 5, 4), PP_ABL(3, true, 5, 16), PP_ABL(3, true, 5, 32), PP_ABL(3, true, 5, 64), PP_ABL(3, true, 5, 128), PP_ABL(3, true, 5, 192),
@@ -967,9 +971,10 @@ int g_attr_lds_f8[kNumTilesF8] = {};
 int g_attr_lds[kNumTiles][2] = {};
 
 // tiles the heuristic may choose from (the rest are explicit / tuning variants); the ping-pong tiles have no conv form
-constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
 int pick_tile(int M, int N, bool conv = false) {
-  // minimise (#rounds over 256 CUs) x (tile area incl. padding waste) / (measured main-loop efficiency of the tile family)
+  // Launch time ~ (tiles the busiest CU runs one after another or side by side) x (tile area incl. padding waste) / (measured
+  // efficiency of the tile family; fitted to tools/gemm_sweep.py over the production and the sequence-parallel shard shapes).
   double best = 1e30;
   int bi = 5;
   for (int i : kAutoList) {
@@ -977,14 +982,15 @@ int pick_tile(int M, int N, bool conv = false) {
     if (conv && !e.conv_fn) continue;
     long tm = (M + e.BM - 1) / e.BM, tn = (N + e.BN - 1) / e.BN;
     long tiles = tm * tn;
-    const bool pp = i >= 6;
-    int per_cu = (!pp && e.lds <= 80 * 1024) ? 2 : 1;
-    long slots = 256L * per_cu;
-    long rounds = (tiles + slots - 1) / slots;
-    // co-resident small tiles run ~concurrently: cost per round ~ per_cu tiles' area, small efficiency bonus for large tiles
-    double eff = (e.BM * e.BN >= 256 * 192) ? 1.0 : (e.BM * e.BN >= 128 * 256 ? 0.9 : 0.8);
+    const bool pp = i >= 6 && i <= 8;
+    const long area = (long)e.BM * e.BN;
+    int per_cu = pp ? 1 : (e.lds <= 40 * 1024 ? 4 : (e.lds <= 80 * 1024 ? 2 : 1));
+    long per_busiest = (tiles + 255) / 256;                       // tiles the busiest CU gets (the dispatcher spreads workgroups)
+    long rounds = (per_busiest + per_cu - 1) / per_cu;            // ... of which per_cu run side by side, sharing the CU
+    long side = per_busiest < per_cu ? per_busiest : per_cu;
+    double eff = area >= 256 * 192 ? 1.0 : (area >= 128 * 256 ? 0.9 : (area >= 128 * 128 ? 0.8 : (area >= 64 * 128 ? 0.5 : 0.55)));
     if (pp) eff = (i == 7) ? 1.20 : 1.14;  // ping-pong main loop: measured +8..14 % (256x192 / 192x256), more at 256x256
-    double cost = (double)rounds * per_cu * e.BM * e.BN / eff;
+    double cost = (double)rounds * side * area / eff;
     if (cost < best - 1e-9) { best = cost; bi = i; }
   }
   return bi;

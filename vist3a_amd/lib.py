@@ -95,6 +95,7 @@ class AttnArgs(C.Structure):
         ("rel_bias", C.c_void_p), ("rel_bias_stride", C.c_int), ("rel_bias_center", C.c_int),
         ("key_bias", C.c_void_p), ("key_bias_stride", C.c_int), ("key_bias_first", C.c_int),
         ("kv_seg", C.c_int), ("k_seg_stride", C.c_long), ("vt_seg_stride", C.c_long),
+        ("kv_split", C.c_int), ("workspace", C.c_void_p),
     ]
 
 
@@ -157,6 +158,7 @@ SYMBOLS = {
     "v3a_gemm_tile_name": (C.c_char_p, [C.c_int]),
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    "v3a_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "v3a_attention_fwd_fp8": (C.c_int, [C.POINTER(AttnFp8Args), C.c_void_p]),
     "v3a_gemm_fp8_nt": (C.c_int, [C.POINTER(GemmFp8Args), C.c_void_p]),
     "v3a_gemm_fp8_num_tiles": (C.c_int, []),

@@ -285,19 +285,30 @@ def conv(
     return out
 
 
+_attn_ws = {}   # per-device workspace of the key-split attention (stream-ordered reuse)
+
+
 def attention(
     q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *,
     B: int, H: int, Nq: int, Nk: int, D: int,
     q_batch_stride: int, k_batch_stride: int, vt_batch_stride: int, o_batch_stride: int,
     scale: Optional[float] = None, kv_period: int = 0, kv_valid: int = 0,
     rel_bias: Optional[torch.Tensor] = None, rel_bias_center: int = 0, key_bias: Optional[torch.Tensor] = None,
-    key_bias_first: int = 0, kv_seg: int = 0, k_seg_stride: int = 0, vt_seg_stride: int = 0,
+    key_bias_first: int = 0, kv_seg: int = 0, k_seg_stride: int = 0, vt_seg_stride: int = 0, kv_split: int = 1,
 ) -> torch.Tensor:
     """q,k,out: 2-D views [B*N, >=H*D] (row stride = their stride(0)); vt: 2-D [H*D, >=B*vt_batch_stride].
     rel_bias (D=64 only): fp32 [H, n] table, entry (key - query + rel_bias_center) is added to the scaled score.
     key_bias (D=128 only): fp32 [B, >=Nk], added to the scaled score of every query (log-multiplicity of merged keys).
     kv_seg (D=128 only): k / vt are the FIRST of Nk / kv_seg equally laid out segments k_seg_stride / vt_seg_stride elements apart
-    (the per-rank slabs of an all-gather), read in place."""
+    (the per-rank slabs of an all-gather), read in place.
+    kv_split > 1 (D=128 only): the keys of every query block are divided among kv_split workgroups whose partial softmaxes a second
+    launch merges - for launches with too few query blocks to fill the chip; deterministic, not bit-identical to kv_split = 1."""
+    ws = None
+    if kv_split > 1:
+        nbytes = L.load().v3a_attention_split_workspace_bytes(B, H, Nq, D, kv_split)
+        ws = _attn_ws.get(q.device)
+        if ws is None or ws.numel() < nbytes:
+            ws = _attn_ws[q.device] = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
     if key_bias is not None and (key_bias.dtype != f32 or key_bias.dim() != 2 or key_bias.shape[0] != B or key_bias.stride(1) != 1):
         raise ValueError("key_bias must be fp32 [B, n] with a contiguous last dim")
     if rel_bias is not None and (rel_bias.dtype != f32 or rel_bias.dim() != 2 or rel_bias.shape[0] != H or not rel_bias.is_contiguous()):
@@ -311,7 +322,7 @@ def attention(
         B, H, Nq, Nk, D, float(scale if scale is not None else D ** -0.5), kv_period, kv_valid,
         _ptr(rel_bias), rel_bias.shape[1] if rel_bias is not None else 0, rel_bias_center,
         _ptr(key_bias), key_bias.stride(0) if key_bias is not None else 0, key_bias_first,
-        kv_seg, k_seg_stride, vt_seg_stride,
+        kv_seg, k_seg_stride, vt_seg_stride, kv_split, _ptr(ws),
     )
     L.check(L.load().v3a_attention_fwd_bf16(C.byref(args), _stream()), "v3a_attention_fwd_bf16")
     return out

@@ -136,7 +136,17 @@ class WanDiT:
         # "fp8" (set by enable_fp8_gemm): the block projections of latent tokens (q/k/v/o, cross q/o, FFN) on e4m3 operands
         # (v3a_gemm_fp8_nt), activations quantised per token and weights per output channel; single-GPU path only.
         self.gemm_dtype = "bf16"
+        # sequence-parallel self-attention: a rank has N / P query rows but every workgroup still walks all N keys, so the launch has
+        # too few workgroups to fill the chip or hide their latency.  None = divide the keys among enough workgroups (kv_split of
+        # v3a_attention_fwd_bf16; deterministic, within bf16 rounding of the unsharded forward); 1 = never (bit-identical to it).
+        self.sp_kv_split: Optional[int] = None
         self._load(state_dict)
+
+    def _sp_split(self, B: int, Nq: int, Nk: int) -> int:
+        if self.sp_kv_split is not None:
+            return max(1, int(self.sp_kv_split))
+        wgs = B * self.cfg.num_attention_heads * ((Nq + 127) // 128)
+        return max(1, min(-(-768 // wgs), (Nk // 64) // 8))   # ~3 workgroups per CU, at least 8 key tiles each
 
     _FP8_WEIGHTS = ("wqk", "wv", "wo", "wq2", "wo2", "w1", "w2")
 
@@ -363,12 +373,12 @@ class WanDiT:
                     # the flash kernel walks the gathered slabs in place: rank r's [K | V^T] pack is segment r (keys r*Nl .. (r+1)*Nl)
                     ops.attention(ws.q, ws.gbuf[0, :Ml * d].view(Ml, d), ws.gbuf[0, Ml * d:].view(d, Ml), ws.ao, B=B, H=H, Nq=Nl, Nk=N,
                                   D=hd, q_batch_stride=Nl * d, k_batch_stride=Nl * d, vt_batch_stride=Nl, o_batch_stride=Nl * d,
-                                  kv_seg=Nl, k_seg_stride=2 * Ml * d, vt_seg_stride=2 * Ml * d)
+                                  kv_seg=Nl, k_seg_stride=2 * Ml * d, vt_seg_stride=2 * Ml * d, kv_split=self._sp_split(B, Nl, N))
                 else:  # ragged shard: reassemble K [B*N, d] and V^T [d, B*N] (two copies per block)
                     ws.kfull.view(B, P, Nl, d).copy_(ws.gbuf[:, :Ml * d].view(P, B, Nl, d).permute(1, 0, 2, 3))
                     vt_full.view(d, B, P, Nl).copy_(ws.gbuf[:, Ml * d:].view(P, d, B, Nl).permute(1, 2, 0, 3))
                     ops.attention(ws.q, ws.kfull, ws.vt, ws.ao, B=B, H=H, Nq=Nl, Nk=N, D=hd, q_batch_stride=Nl * d,
-                                  k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=Nl * d)
+                                  k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=Nl * d, kv_split=self._sp_split(B, Nl, N))
             lin.last = None
             lin(ws.ao, b, "wo", b["bo"], out=x, residual=x, scale=m[:, 2], rows_per_batch=Nl)
             # --- cross attention
