@@ -979,7 +979,7 @@ int pick_tile(int M, int N, bool conv = false) {
   int bi = 5;
   for (int i : kAutoList) {
     const TileEntry& e = kTiles[i];
-    if (conv && !e.conv_fn) continue;
+    if (conv && (!e.conv_fn || i >= 9)) continue;   // (the small tiles were fitted on GEMM shards only: convolutions keep their tiles)
     long tm = (M + e.BM - 1) / e.BM, tn = (N + e.BN - 1) / e.BN;
     long tiles = tm * tn;
     const bool pp = i >= 6 && i <= 8;
