@@ -1,0 +1,27 @@
+#!/bin/bash
+# One gpurun call that regenerates everything under profiles/rN (summaries only: the per-dispatch traces are deleted on the box).
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh'   then copy gpurun_out/prof_* into profiles/rN/
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+O=$R/gpurun_out
+mkdir -p $O
+python -m pytest tests -q -m gpu -s > $O/prof_gputest_stdout.log 2>&1
+tail -3 $O/prof_gputest_stdout.log
+cp $O/parity.json $O/prof_parity.json
+python bench.py 2>/dev/null | tail -1 > $O/prof_bench_default_run.json
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/prof_bench_under_rocprof.json
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/prof_bench_kernel_stats.csv
+python $R/tools/trace_shapes.py /tmp/prof_stats 45 > $O/prof_bench_kernel_shapes.txt
+rm -rf /tmp/prof_stats
+cd $R
+bash tools/pmc_traffic.sh > /dev/null 2>&1; cp $O/pmc_traffic.json $O/prof_pmc_traffic.json; rm -rf $O/pmc_traffic_FETCH_SIZE $O/pmc_traffic_WRITE_SIZE
+bash tools/pmc_mfma.sh > /dev/null 2>&1; cp $O/pmc_mfma.json $O/prof_pmc_mfma.json; rm -rf $O/pmc_mfma
+python tools/dit14b_time.py 2>/dev/null | tail -4 > $O/prof_dit14b.jsonl
+python tools/sp_rank_time.py 2>/dev/null | tail -8 > $O/prof_sp_rank_time_1_3b.jsonl
+python tools/sp_rank_time.py 14b 2>/dev/null | tail -8 > $O/prof_sp_rank_time_14b.jsonl
+python tools/gemm_sweep.py 6,8,7 0,1,2,3,4,8 2>/dev/null | grep "^{" > $O/prof_gemm_sweep.jsonl
+python tools/gemm_fp8_time.py 2>/dev/null | grep "^{" > $O/prof_gemm_fp8.jsonl
+python tools/attn_time.py 2>/dev/null | tail -1 > $O/prof_attn_time.json
+ls -la $O | head -40

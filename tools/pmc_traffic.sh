@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] == c:
                 acc[k] += float(r["Counter_Value"]); n[k] += 1
     for k in acc:
-        if "gemm_pp_kernel" in k or "attn_fwd_kernel3<128" in k:
+        if "gemm_pp_kernel" in k or "attn_fwd_kernel<128, 4, false, false, true>" in k:
             key = k.replace("void (anonymous namespace)::", "").replace("((anonymous namespace)::GemmP)", "").replace("((anonymous namespace)::AttnP)", "")
             out.setdefault(key, {})[c + "_KiB_avg"] = acc[k] / n[k]
             out[key]["launches"] = n[k]
