@@ -40,6 +40,8 @@ def timed(fn, n=5):
 if __name__ == "__main__":
     cfg = WAN_14B if "14b" in sys.argv[1:] else WAN_1_3B
     m = WanDiT(cfg, random_dit_state_dict(cfg, seed=0, device="cuda"))
+    if "fp8" in sys.argv[1:]:   # e4m3 block GEMMs (the sharded path keeps the bf16 key-split attention)
+        m.enable_fp8_gemm()
     text = torch.zeros(1, 512, 4096, device="cuda")
     text[0, :64] = torch.randn(64, 4096, device="cuda") * 0.1
     t = torch.tensor([900], device="cuda")

@@ -432,7 +432,7 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   if (!a->kv_seg && a->vt_batch_stride && a->vt_batch_stride < a->Nk && a->B > 1) return V3A_ERR_SHAPE;
   if (a->kv_seg > 0 && a->vt_batch_stride && a->vt_batch_stride < a->kv_seg && a->B > 1) return V3A_ERR_SHAPE;
   if (a->kv_period < 0 || (a->kv_period > 0 && (a->kv_valid <= 0 || a->kv_valid > a->kv_period))) return V3A_ERR_ARG;
-  AttnP p;
+  AttnP p = {};   // every optional feature off unless set below (the relative-bias launch returns before most of them)
   p.q = (const char*)a->q; p.k = (const char*)a->k; p.vt = (const char*)a->vt; p.o = (char*)a->o;
   p.q_bs = a->q_batch_stride; p.k_bs = a->k_batch_stride; p.vt_bs = a->vt_batch_stride; p.o_bs = a->o_batch_stride;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;
@@ -441,6 +441,7 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   p.kv_period = a->kv_period; p.kv_valid = a->kv_valid;
   p.relb = a->rel_bias; p.relb_stride = a->rel_bias_stride; p.relb_center = a->rel_bias_center;
   p.inv_scale = 1.0f / a->scale;
+  p.B = a->B; p.kv_split = 1;
   if (a->rel_bias) {  // needs table entries for every (key - query) in [-(Nq-1), Nk-1]
     if (a->D != 64 || a->rel_bias_center < a->Nq - 1 || a->rel_bias_stride < a->rel_bias_center + a->Nk) return V3A_ERR_SHAPE;
     return launch_attn<64, 4, true, false, false>(p, a->B, stream);

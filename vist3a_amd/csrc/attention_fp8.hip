@@ -330,7 +330,7 @@ extern "C" int v3a_attention_fwd_fp8(const v3a_attn_fp8_args* a, void* stream) {
   if (a->ldq % 16 || a->ldk % 16 || a->ldvt % 16 || a->ldo % 8) return V3A_ERR_SHAPE;
   if (a->q_batch_stride % 16 || a->k_batch_stride % 16 || a->vt_batch_stride % 16 || a->o_batch_stride % 8) return V3A_ERR_SHAPE;
   if (!(a->q_scale > 0.f) || !(a->k_scale > 0.f) || !(a->v_scale > 0.f)) return V3A_ERR_ARG;
-  Attn8P p;
+  Attn8P p = {};
   p.q = (const char*)a->q; p.k = (const char*)a->k; p.vt = (const char*)a->vt; p.o = (char*)a->o;
   p.q_bs = a->q_batch_stride; p.k_bs = a->k_batch_stride; p.vt_bs = a->vt_batch_stride; p.o_bs = a->o_batch_stride;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldvt = a->ldvt; p.ldo = a->ldo;

@@ -289,7 +289,7 @@ extern "C" int v3a_layernorm(const v3a_layernorm_args* a, void* stream) {
   if (!a || !a->x || !a->y) return V3A_ERR_ARG;
   if (a->M <= 0 || a->d <= 0 || a->d % 8 || a->ldx % 8 || a->ldy % 8) return V3A_ERR_SHAPE;
   if ((a->scale == nullptr) != (a->shift == nullptr)) return V3A_ERR_ARG;
-  LnP p;
+  LnP p = {};
   p.x = (const char*)a->x; p.y = (char*)a->y; p.w = a->weight; p.b = a->bias;
   p.scale = a->scale; p.shift = a->shift;
   p.M = a->M; p.d = a->d; p.ldx = a->ldx; p.ldy = a->ldy;
@@ -309,7 +309,7 @@ extern "C" int v3a_rmsnorm_rope(const v3a_rmsnorm_rope_args* a, void* stream) {
   if (!a || !a->x || !a->y || !a->weight) return V3A_ERR_ARG;
   if (a->M <= 0 || a->d <= 0 || a->d % 8 || a->ldx % 8 || a->ldy % 8) return V3A_ERR_SHAPE;
   if (a->rope && (a->head_dim <= 0 || a->head_dim % 8 || a->d % a->head_dim)) return V3A_ERR_SHAPE;
-  RmsP p;
+  RmsP p = {};
   p.x = (const char*)a->x; p.y = (char*)a->y; p.w = a->weight; p.rope = a->rope;
   p.M = a->M; p.d = a->d; p.ldx = a->ldx; p.ldy = a->ldy;
   p.hd = a->head_dim > 0 ? a->head_dim : a->d;
@@ -334,7 +334,7 @@ extern "C" int v3a_rownorm_act(const v3a_rownorm_args* a, void* stream) {
     if (waste < best_waste) { best_waste = waste; best_cpl = cpl; best_lpr = lpr; }
   }
   if (!best_cpl) return V3A_ERR_SHAPE;
-  RowNormP p;
+  RowNormP p = {};
   p.x = (const char*)a->x; p.y = (char*)a->y; p.w = a->weight; p.b = a->bias;
   p.M = a->M; p.d = a->d; p.ldx = a->ldx; p.ldy = a->ldy; p.lpr = best_lpr; p.mode = a->mode; p.act = a->act;
   p.eps = a->eps;

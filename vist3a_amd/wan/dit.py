@@ -96,6 +96,7 @@ class _Workspace:
         d, M = cfg.dim, B * Nl
         e = lambda *s, dt=bf16: torch.empty(*s, device=device, dtype=dt)
         self.B, self.N, self.M = B, Nl, M
+        self.a8 = self.sa = self.h8 = self.sh = None   # e4m3 activations + per-token scales, allocated on first use of the fp8 GEMM mode
         self.x = e(M, d)
         self.n = e(M, d)
         self.q2 = e(M, d)
@@ -107,7 +108,6 @@ class _Workspace:
             self.qk = e(M, 2 * d)
             self.vt = torch.zeros(d, B * ((N + 63) // 64 * 64), device=device, dtype=bf16)
             self.qk8 = self.vt8 = None   # e4m3 copies, allocated on first use of the fp8 attention mode
-            self.a8 = self.sa = self.h8 = self.sh = None   # e4m3 activations + per-token scales of the fp8 GEMM mode
         else:  # sequence-parallel: local q, packed local [K | V^T] to send, gathered slabs, full K / V^T
             self.q = e(M, d)
             self.pack = e(2 * M * d)
@@ -134,7 +134,8 @@ class WanDiT:
         self.attn_dtype = "bf16"
         self.fp8_scales = (1.0, 1.0, 1.0)
         # "fp8" (set by enable_fp8_gemm): the block projections of latent tokens (q/k/v/o, cross q/o, FFN) on e4m3 operands
-        # (v3a_gemm_fp8_nt), activations quantised per token and weights per output channel; single-GPU path only.
+        # (v3a_gemm_fp8_nt), activations quantised per token and weights per output channel (token-local: the sequence-parallel
+        # path runs them on its shard unchanged).
         self.gemm_dtype = "bf16"
         # sequence-parallel self-attention: a rank has N / P query rows but every workgroup still walks all N keys, so the launch has
         # too few workgroups to fill the chip or hide their latency.  None = divide the keys among enough workgroups (kv_split of
@@ -152,7 +153,7 @@ class WanDiT:
 
     def enable_fp8_gemm(self) -> "WanDiT":
         """Quantise the block projection weights to e4m3 with one scale per output channel (kept beside the bf16 weights, which the
-        sequence-parallel path and the per-prompt text K / V projections still use) and switch the block GEMMs to v3a_gemm_fp8_nt."""
+        per-prompt text K / V projections still use) and switch the block GEMMs to v3a_gemm_fp8_nt."""
         if self.cfg.dim % 128 or self.cfg.ffn_dim % 128:
             raise ValueError("fp8 GEMMs need K % 128 == 0")
         for b in self.blocks:
@@ -304,8 +305,6 @@ class WanDiT:
             vt_full = ws.vt[:, :B * N]
         g8 = self.gemm_dtype == "fp8"
         if g8:
-            if P != 1:
-                raise NotImplementedError("the fp8 GEMM mode covers the single-GPU path")
             if ws.a8 is None:
                 ws.a8, ws.sa = torch.empty(Ml, d, device=self.device, dtype=torch.uint8), torch.empty(Ml, device=self.device, dtype=f32)
                 ws.h8, ws.sh = torch.empty(Ml, cfg.ffn_dim, device=self.device, dtype=torch.uint8), torch.empty(Ml, device=self.device, dtype=f32)
@@ -362,11 +361,20 @@ class WanDiT:
                                   k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d)
             else:
                 # K and V^T of the local tokens first, so their all-gather rides under the Q projection
-                ops.gemm(ws.n, b["wqk"][d:], b["bqk"][d:], out=kl)
+                if g8:   # (norm() left the e4m3 tokens and their scales in ws.a8 / ws.sa)
+                    ops.gemm(ws.a8, b["wqk8"][d:], b["bqk"][d:], out=kl, a_scale=ws.sa, w_scale=b["swqk"][d:])
+                else:
+                    ops.gemm(ws.n, b["wqk"][d:], b["bqk"][d:], out=kl)
                 ops.rmsnorm_rope(kl, b["nk"], out=kl, rope=rope, head_dim=hd, tokens_per_batch=Nl, eps=cfg.eps)
-                ops.gemm(b["wv"], ws.n, b["bv"], out=vtl, bias_row=True)
+                if g8:
+                    ops.gemm(b["wv8"], ws.a8, b["bv"], out=vtl, bias_row=True, a_scale=b["swv"], w_scale=ws.sa)
+                else:
+                    ops.gemm(b["wv"], ws.n, b["bv"], out=vtl, bias_row=True)
                 pending = sp.all_gather(ws.gbuf, ws.pack)
-                ops.gemm(ws.n, b["wqk"][:d], b["bqk"][:d], out=ws.q)
+                if g8:
+                    ops.gemm(ws.a8, b["wqk8"][:d], b["bqk"][:d], out=ws.q, a_scale=ws.sa, w_scale=b["swqk"][:d])
+                else:
+                    ops.gemm(ws.n, b["wqk"][:d], b["bqk"][:d], out=ws.q)
                 ops.rmsnorm_rope(ws.q, b["nq"], out=ws.q, rope=rope, head_dim=hd, tokens_per_batch=Nl, eps=cfg.eps)
                 pending.wait()
                 if Nl % 64 == 0:
