@@ -23,7 +23,9 @@ struct LnP {
   float* y_scale;               // non-null: e4m3 output with per-row dynamic scale
 };
 
-template <int CPL>
+// F8OUT: e4m3 output with per-row scales (a separate instantiation: its extra live registers would cost the bf16 kernel a wave per
+// SIMD, and 8192 rows are exactly 8 waves per SIMD - one round)
+template <int CPL, bool F8OUT = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
   const int lane = threadIdx.x & 63;
   const int row0 = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[e] = o[e] * (1.f + s0[e]) + h0[e]; o[4 + e] = o[4 + e] * (1.f + s1[e]) + h1[e]; }
     }
-    if (p.y_scale) {   // keep the bf16-rounded result in registers; the row maximum decides the e4m3 scale below
+    if constexpr (F8OUT) {   // keep the bf16-rounded result in registers; the row maximum decides the e4m3 scale below
       unpack_bf16x8(pack_bf16x8(o), v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
       *(u32x4*)(p.y + (orow * p.ldy + c * 8) * 2) = pack_bf16x8(o);
     }
   }
-  if (p.y_scale) {   // same arithmetic as quantize_fp8_rows_kernel (attention_fp8.hip) on the bf16 row
+  if constexpr (F8OUT) {   // same arithmetic as quantize_fp8_rows_kernel (attention_fp8.hip) on the bf16 row
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     const float sc = fmaxf(amax, 1e-12f) / 448.0f;
@@ -301,6 +303,13 @@ extern "C" int v3a_layernorm(const v3a_layernorm_args* a, void* stream) {
   p.y_scale = a->y_fp8_scale;
   if (p.y_scale && p.y_f32) return V3A_ERR_ARG;
   const dim3 grid((a->M + 3) / 4);
+  if (p.y_scale) {
+    const int cpl = (a->d / 8 + 63) / 64;
+    if (cpl <= 3) hipLaunchKernelGGL((layernorm_kernel<3, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (cpl <= 10) hipLaunchKernelGGL((layernorm_kernel<10, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else return V3A_ERR_SHAPE;
+    return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+  }
   DISPATCH_CPL(layernorm_kernel, p, a->d, grid, stream);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
