@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 11) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 12) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -69,8 +69,13 @@ typedef struct {
   int ldr2;
   int res_row_mod;      /* > 0: `residual` row index is (row % res_row_mod): broadcast table (positional embedding) */
   int out_row_group, out_row_skip, out_row_off; /* group > 0: output row = row + (row / group) * skip + off */
+  int split_k;          /* > 1 (v3a_gemm_bf16_nt only): K is cut into split_k equal slices (K % (64 * split_k) == 0) computed side by side
+                         * into bf16 partials, summed in slice order by a second launch that applies the epilogue - for problems with
+                         * few output tiles and a long K (a sequence-parallel shard's FFN2).  Deterministic; not bit-identical to 0 / 1. */
+  void* workspace;      /* split_k > 1: v3a_gemm_split_workspace_bytes(M, N, split_k) bytes */
 } v3a_gemm_args;
 int v3a_gemm_bf16_nt(const v3a_gemm_args* args, void* stream);
+size_t v3a_gemm_split_workspace_bytes(int M, int N, int split_k);
 int v3a_gemm_num_tiles(void);
 int v3a_gemm_pick_tile(int M, int N);   /* the tile index tile=-1 resolves to (profiling / roofline bookkeeping) */
 const char* v3a_gemm_tile_name(int tile);

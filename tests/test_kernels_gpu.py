@@ -139,6 +139,34 @@ def test_gemm_epilogue_flags_every_tile(hip_lib, parity):
                 assert torch.equal(out, first), (tn, c)
 
 
+@pytest.mark.parametrize("M,N,K,S,opt", [(1024, 1536, 8960, 4, dict(res=True, scale=True)), (512, 1536, 8960, 2, dict(act="gelu")),
+                                         (1000, 520, 1024, 4, dict(bias_row=True, out_f32=True)), (2048, 5120, 13824, 2, {})])
+def test_gemm_split_k_matches_unsplit(hip_lib, parity, M, N, K, S, opt):
+    """split_k (a sequence-parallel shard's long-K FFN2): S K-slices side by side + the finishing launch against the fp32 reference
+    with the documented rounding points and against the one-launch kernel (one extra bf16 rounding per partial apart); deterministic."""
+    from vist3a_amd import lib as L, ops
+    g = torch.Generator(device=dev).manual_seed(M + S)
+    a = torch.randn(M, K, device=dev, generator=g).to(bf16)
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(bf16)
+    bias_row, out_f32 = opt.get("bias_row", False), opt.get("out_f32", False)
+    bias = torch.randn(M if bias_row else N, device=dev, generator=g)
+    act = L.ACT_GELU_TANH if opt.get("act") == "gelu" else L.ACT_NONE
+    res = torch.randn(M, N, device=dev, generator=g).to(bf16) if opt.get("res") else None
+    scale = torch.randn(2, N, device=dev, generator=g) if opt.get("scale") else None
+    rpb = M // 2 if scale is not None else 0
+    kw = dict(act=act, residual=res, scale=scale, rows_per_batch=rpb, bias_row=bias_row, out_f32=out_f32)
+    one = ops.gemm(a, w, bias, **kw)
+    s1 = ops.gemm(a, w, bias, split_k=S, **kw)
+    s2 = ops.gemm(a, w, bias, split_k=S, **kw)
+    ref = gemm_ref(L, a, w, bias, act, res, scale, rpb, False, bias_row, out_f32)
+    r, r1 = relerr(s1, ref), relerr(s1, one)
+    parity("gemm_split_k", M=M, N=N, K=K, S=S, rel_vs_fp32=r, rel_vs_one_launch=r1)
+    assert torch.equal(s1, s2)
+    assert r < 4e-3 and r1 < 4e-3, (r, r1)   # bf16 partials: ~sqrt(2) x one output rounding (2.2e-3)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a[:, :192], w[:, :192], None, split_k=2)   # K % (64 * split_k) != 0
+
+
 def test_gemm_rejects_unknown_flag_bits(hip_lib):
     from vist3a_amd import ops
     import ctypes as C

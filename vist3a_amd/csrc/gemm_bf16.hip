@@ -47,6 +47,8 @@ struct GemmP {
   // e4m3 operands (gemm_pp_kernel<.., F8 = true> only): per-row dequantisation scales of A and B (fp32), applied to the accumulators
   const float* a_scale;   // [M]
   const float* b_scale;   // [N]
+  // blockIdx.y = z selects one of several equally shaped problems (split-K slices): byte offsets of A, B, C per z
+  long az, bz, cz;
 };
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -350,7 +352,9 @@ __device__ __forceinline__ void gemm_add_bias(const GemmP& p, f32x16 (&acc)[MT][
 //          occupies its wave for ~100+ cycles at issue and every wave of the workgroup issues them at the same point, so
 //          DMA staging leaves the matrix pipe idle for ~40 % of each slab (measured: 1468 TF without refill vs 830 with).
 template <int BM, int BN, int WM, int WN, int BK, int NS, bool CONV, int STG>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel(const GemmP p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel(const GemmP pin) {
+  GemmP p = pin;
+  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; }
   using T = TileCfg<BM, BN, WM, WN, BK, NS>;
   constexpr int NW = T::NW, MT = T::MT, NTL = T::NTL, NL = T::NL, STAGE = T::STAGE;
   constexpr int WTM = T::WTM, WTN = T::WTN, PITCH = T::PITCH;
@@ -647,7 +651,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // ABL (development ablations, -DV3A_GEMM_ABL builds only; results are garbage): bit 0 = no LDS-DMA in the K loop, bit 1 = no
 // fragment reads, bit 2 = no MFMAs, bit 3 = no s_setprio.
 template <int NP, bool RA, int LEAD, int ABL = 0, bool F8 = false>
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP p) {
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP pin) {
+  GemmP p = pin;
+  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; }
   using T = PPCfg<NP>;
   constexpr int RB = T::RB, STAGE = T::STAGE, J = T::J;
   constexpr int BM = RA ? 256 : 64 * NP, BN = RA ? 64 * NP : 256;
@@ -972,7 +978,7 @@ int g_attr_lds[kNumTiles][2] = {};
 
 // tiles the heuristic may choose from (the rest are explicit / tuning variants); the ping-pong tiles have no conv form
 constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-int pick_tile(int M, int N, bool conv = false) {
+int pick_tile(int M, int N, bool conv = false, int mult = 1) {
   // Launch time ~ (tiles the busiest CU runs one after another or side by side) x (tile area incl. padding waste) / (measured
   // efficiency of the tile family; fitted to tools/gemm_sweep.py over the production and the sequence-parallel shard shapes).
   double best = 1e30;
@@ -981,7 +987,7 @@ int pick_tile(int M, int N, bool conv = false) {
     const TileEntry& e = kTiles[i];
     if (conv && (!e.conv_fn || i >= 9)) continue;   // (the small tiles were fitted on GEMM shards only: convolutions keep their tiles)
     long tm = (M + e.BM - 1) / e.BM, tn = (N + e.BN - 1) / e.BN;
-    long tiles = tm * tn;
+    long tiles = tm * tn * mult;   // (mult: split-K slices launched side by side)
     const bool pp = i >= 6 && i <= 8;
     const long area = (long)e.BM * e.BN;
     int per_cu = pp ? 1 : (e.lds <= 40 * 1024 ? 4 : (e.lds <= 80 * 1024 ? 2 : 1));
@@ -996,8 +1002,8 @@ int pick_tile(int M, int N, bool conv = false) {
   return bi;
 }
 
-int launch(const GemmP& p, int ti, bool conv, void* stream) {
-  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N, conv);
+int launch(const GemmP& p, int ti, bool conv, void* stream, int nz = 1) {
+  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N, conv, nz);
   const TileEntry& e = kTiles[ti];
   const gemm_fn fn = conv ? e.conv_fn : e.fn;
   if (!fn) return V3A_ERR_ARG;  // this tile shape has no conv instantiation
@@ -1009,7 +1015,7 @@ int launch(const GemmP& p, int ti, bool conv, void* stream) {
     g_attr_lds[ti][conv] = lds;
   }
   const long tiles = (long)((p.M + e.BM - 1) / e.BM) * ((p.N + e.BN - 1) / e.BN);
-  hipLaunchKernelGGL(fn, dim3((unsigned)tiles), dim3(e.nthr), lds, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(fn, dim3((unsigned)tiles, (unsigned)nz), dim3(e.nthr), lds, (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
@@ -1035,6 +1041,79 @@ int launch_f8(const GemmP& p, int ti, void* stream) {
   const long tiles = (long)((p.M + e.BM - 1) / e.BM) * ((p.N + e.BN - 1) / e.BN);
   hipLaunchKernelGGL(e.fn, dim3((unsigned)tiles), dim3(e.nthr), e.lds, (hipStream_t)stream, p);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}
+
+// Second launch of a split-K GEMM: C = epilogue(sum_z partial_z), partials bf16 [S][M][N] summed in fp32 in the order z = 0 .. S-1
+// (deterministic), then the documented epilogue order of v3a_gemm_bf16_nt.  One thread per 8 columns.
+struct SplitFinP {
+  const char* part; char* C; const float* bias; const char* res; const float* scale; const char* res2;
+  int M, N, S, ldc, ldr, ldr2, rpb, sstride, act, flags, res_mod, og, os, oo;
+};
+__global__ __launch_bounds__(256) void gemm_splitk_finish_kernel(const SplitFinP p) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int cpr = p.N / 8;
+  if (idx >= (long)p.M * cpr) return;
+  const int m = (int)(idx / cpr), n = (int)(idx % cpr) * 8;
+  float v[8] = {};
+  for (int z = 0; z < p.S; ++z) {
+    float f[8];
+    unpack_bf16x8(*(const u32x4*)(p.part + (((size_t)z * p.M + m) * p.N + n) * 2), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += f[e];
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += (p.flags & V3A_GEMM_BIAS_ROW) ? p.bias[m] : p.bias[n + e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float x = round_bf16(v[e]);
+    if (p.act != V3A_ACT_NONE) {
+      x = p.act == V3A_ACT_GELU_TANH ? gelu_tanh(x) : p.act == V3A_ACT_GELU_ERF ? gelu_erf(x) : p.act == V3A_ACT_SILU ? silu(x) : fmaxf(x, 0.f);
+      x = round_bf16(x);
+    }
+    v[e] = x;
+  }
+  if (p.scale) {
+    const float* sp = p.scale + ((p.flags & V3A_GEMM_SCALE_PER_BATCH) ? (size_t)(m / p.rpb) * p.sstride : 0) + n;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= sp[e];
+    if (p.flags & V3A_GEMM_ROUND_AFTER_SCALE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = round_bf16(v[e]);
+    }
+  }
+  if (p.res) {
+    const int mr = p.res_mod > 0 ? m % p.res_mod : m;
+    if (p.flags & V3A_GEMM_RES_F32) {
+      const float* rp = (const float*)p.res + (size_t)mr * p.ldr + n;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rp[e];
+    } else {
+      float f[8];
+      unpack_bf16x8(*(const u32x4*)(p.res + ((size_t)mr * p.ldr + n) * 2), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += f[e];
+    }
+  }
+  if (p.res2) {
+    float f[8];
+    unpack_bf16x8(*(const u32x4*)(p.res2 + ((size_t)m * p.ldr2 + n) * 2), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += f[e];
+  }
+  if (p.flags & V3A_GEMM_RELU_OUT) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  const size_t mo = p.og > 0 ? (size_t)m + (size_t)(m / p.og) * p.os + p.oo : (size_t)m;
+  if (p.flags & V3A_GEMM_OUT_F32) {
+    float* cp = (float*)p.C + mo * p.ldc + n;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cp[e] = v[e];
+  } else {
+    *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = pack_bf16x8(v);
+  }
 }
 
 constexpr int kKnownFlags = V3A_GEMM_BIAS_ROW | V3A_GEMM_SCALE_PER_BATCH | V3A_GEMM_ROUND_AFTER_SCALE | V3A_GEMM_RES_F32 |
@@ -1064,7 +1143,27 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   p.res2 = (const char*)a->residual2; p.ldr2 = a->ldr2; p.res_mod = a->res_row_mod;
   p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
   if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
+  if (a->split_k < 0) return V3A_ERR_ARG;
+  if (a->split_k > 1) {   // S equally long K slices side by side (blockIdx.y), bf16 partials, then the epilogue in a second launch
+    const int S = a->split_k;
+    if (!a->workspace || a->K % (64 * S)) return V3A_ERR_ARG;
+    GemmP q = {};
+    q.A = p.A; q.B = p.B; q.C = (char*)a->workspace;
+    q.M = p.M; q.N = p.N; q.K = p.K / S; q.lda = p.lda; q.ldb = p.ldb; q.ldc = p.N; q.rpb = 1;
+    q.az = (long)q.K * 2; q.bz = (long)q.K * 2; q.cz = (long)p.M * p.N * 2;
+    const int rc = launch(q, a->tile, false, stream, S);
+    if (rc != V3A_OK) return rc;
+    SplitFinP f = {(const char*)a->workspace, p.C, p.bias, p.res, p.scale, p.res2, p.M, p.N, S, p.ldc, p.ldr, p.ldr2, p.rpb, p.sstride,
+                   p.act, p.flags, p.res_mod, p.orow_group, p.orow_skip, p.orow_off};
+    const long n = (long)p.M * (p.N / 8);
+    hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f);
+    return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+  }
   return launch(p, a->tile, false, stream);
+}
+
+extern "C" size_t v3a_gemm_split_workspace_bytes(int M, int N, int split_k) {
+  return (M > 0 && N > 0 && split_k > 1) ? (size_t)split_k * M * N * 2 : 0;
 }
 
 extern "C" int v3a_gemm_fp8_num_tiles(void) { return kNumTilesF8; }
@@ -1082,6 +1181,7 @@ extern "C" int v3a_gemm_fp8_nt(const v3a_gemm_fp8_args* f, void* stream) {
   if ((a->flags & V3A_GEMM_SCALE_PER_BATCH) && a->scale && a->rows_per_batch <= 0) return V3A_ERR_ARG;
   if (a->flags & ~kKnownFlags) return V3A_ERR_ARG;
   if (a->flags & V3A_GEMM_NO_ROUND_ACC) return V3A_ERR_ARG;
+  if (a->split_k > 1) return V3A_ERR_ARG;   // (bf16 entry only)
   GemmP p = {};
   p.A = (const char*)a->A; p.B = (const char*)a->B; p.C = (char*)a->C;
   p.bias = a->bias; p.res = (const char*)a->residual; p.scale = a->scale;

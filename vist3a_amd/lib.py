@@ -32,6 +32,7 @@ class GemmArgs(C.Structure):
         ("act", C.c_int), ("flags", C.c_int), ("tile", C.c_int),
         ("residual2", C.c_void_p), ("ldr2", C.c_int), ("res_row_mod", C.c_int),
         ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
+        ("split_k", C.c_int), ("workspace", C.c_void_p),
     ]
 
 
@@ -160,6 +161,7 @@ SYMBOLS = {
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "v3a_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "v3a_attention_fwd_fp8": (C.c_int, [C.POINTER(AttnFp8Args), C.c_void_p]),
+    "v3a_gemm_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "v3a_gemm_fp8_nt": (C.c_int, [C.POINTER(GemmFp8Args), C.c_void_p]),
     "v3a_gemm_fp8_num_tiles": (C.c_int, []),
     "v3a_gemm_fp8_pick_tile": (C.c_int, [C.c_int, C.c_int]),

@@ -56,6 +56,9 @@ def set_gemm_probe(p: Optional[GemmProbe]) -> None:
     _probe = p
 
 
+_gemm_ws = {}   # per-device split-K partial buffer (stream-ordered reuse)
+
+
 def gemm(
     a: torch.Tensor,
     w: torch.Tensor,
@@ -76,11 +79,13 @@ def gemm(
     out_rows: Optional[tuple] = None,
     a_scale: Optional[torch.Tensor] = None,
     w_scale: Optional[torch.Tensor] = None,
+    split_k: int = 1,
 ) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T); see v3a_gemm_bf16_nt for the epilogue order.
     out_rows=(group, skip, off) scatters output row m to m + (m//group)*skip + off (out must be given).
 
     scale: f32 [N] (LayerScale) or [nbatch, N] together with rows_per_batch (AdaLN gate).
+    split_k > 1 (bf16 only): K cut into split_k slices computed side by side, summed by a second launch (few output tiles, long K).
     a_scale / w_scale (f32 [M] / [N]): a and w are e4m3 bytes from `quantize_fp8_rows`; runs v3a_gemm_fp8_nt (tile then indexes its tiles)."""
     in_dt = (bf16,) if a_scale is None else (torch.uint8, torch.float8_e4m3fn)
     _chk2d(a, "a", in_dt)
@@ -95,7 +100,7 @@ def gemm(
         out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
     _chk2d(out, "out", (f32,) if out_f32 else (bf16,))
     # weight-streaming shapes (<= 128 rows against a big matrix) go to the skinny kernel: the tile GEMM would occupy N/128 CUs
-    plain = a_scale is None and scale is None and residual2 is None and out_rows is None and not relu_out and tile < 0 and res_row_mod == 0
+    plain = split_k <= 1 and a_scale is None and scale is None and residual2 is None and out_rows is None and not relu_out and tile < 0 and res_row_mod == 0
     if plain and K % 512 == 0 and K >= 1024:
         if M <= 128 and N >= 512 and not bias_row:
             return _gemm_skinny(a, w, bias, out, act, residual, out_f32, transposed=False)
@@ -135,6 +140,14 @@ def gemm(
         _ptr(residual2), residual2.stride(0) if residual2 is not None else 0, res_row_mod,
         *(out_rows if out_rows is not None else (0, 0, 0)),
     )
+    if split_k > 1:
+        if a_scale is not None:
+            raise ValueError("split_k applies to the bf16 GEMM")
+        nbytes = L.load().v3a_gemm_split_workspace_bytes(M, N, split_k)
+        ws = _gemm_ws.get(a.device)
+        if ws is None or ws.numel() < nbytes:
+            ws = _gemm_ws[a.device] = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
+        args.split_k, args.workspace = split_k, ws.data_ptr()
     if a_scale is not None:
         for t, n, nm in ((a_scale, M, "a_scale"), (w_scale, N, "w_scale")):
             if t is None or t.dtype != f32 or not t.is_contiguous() or t.numel() != n:

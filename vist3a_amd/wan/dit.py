@@ -139,9 +139,19 @@ class WanDiT:
         self.gemm_dtype = "bf16"
         # sequence-parallel self-attention: a rank has N / P query rows but every workgroup still walks all N keys, so the launch has
         # too few workgroups to fill the chip or hide their latency.  None = divide the keys among enough workgroups (kv_split of
-        # v3a_attention_fwd_bf16; deterministic, within bf16 rounding of the unsharded forward); 1 = never (bit-identical to it).
+        # v3a_attention_fwd_bf16; deterministic, within bf16 rounding of the unsharded forward) and split the K of its FFN2 GEMM;
+        # 1 = never (bit-identical to the unsharded forward).
         self.sp_kv_split: Optional[int] = None
         self._load(state_dict)
+
+    def _sp_ksplit(self, M: int, N: int, K: int) -> int:
+        """split-K factor of a shard's long-K projection (FFN2): few output tiles, 140 K tiles each - unless the exact mode is on"""
+        if self.sp_kv_split == 1 or M > 2048 or K < 4096:
+            return 1
+        for S in (4, 2):
+            if K % (64 * S) == 0 and (M // 64) * (N // 64) * S <= 2048:
+                return S
+        return 1
 
     def _sp_split(self, B: int, Nq: int, Nk: int) -> int:
         if self.sp_kv_split is not None:
@@ -401,7 +411,10 @@ class WanDiT:
             # --- feed forward
             norm(scale=m[:, 4], shift=m[:, 3], rows_per_batch=Nl)
             lin(ws.n, b, "w1", b["b1"], out=ws.h, act=L.ACT_GELU_TANH)
-            lin(ws.h, b, "w2", b["b2"], out=x, residual=x, scale=m[:, 5], rows_per_batch=Nl)
+            if P > 1 and not g8 and self._sp_ksplit(Ml, d, cfg.ffn_dim) > 1:
+                ops.gemm(ws.h, b["w2"], b["b2"], out=x, residual=x, scale=m[:, 5], rows_per_batch=Nl, split_k=self._sp_ksplit(Ml, d, cfg.ffn_dim))
+            else:
+                lin(ws.h, b, "w2", b["b2"], out=x, residual=x, scale=m[:, 5], rows_per_batch=Nl)
 
         om = (self.out_sst[None] + temb.float()[:, None]).contiguous()  # [B,2,d]
         ops.layernorm(x, out=ws.n, scale=om[:, 1], shift=om[:, 0], rows_per_batch=Nl, eps=cfg.eps)
