@@ -215,6 +215,8 @@ typedef struct {
   const float* rope;          /* or NULL */
   int M, d, ldx, ldy, head_dim, tokens_per_batch;
   float eps;
+  const float* weight2;       /* non-NULL: a SECOND column block x[:, d:2d] -> y[:, d:2d] normalised with weight2 in the same launch
+                               * (q and k of the fused q|k projection: one launch instead of two) */
 } v3a_rmsnorm_rope_args;
 int v3a_rmsnorm_rope(const v3a_rmsnorm_rope_args* args, void* stream);
 

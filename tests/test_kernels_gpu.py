@@ -437,6 +437,14 @@ def test_norm_kernels_production_shapes(hip_lib, parity):
         r = relerr(y, torch.view_as_real(nc * fc).reshape(M, d).to(bf16))
         parity("rmsnorm_rope", B=B, N=N, rel_vs_fp32=r)
         assert r < 6e-5, r   # measured 2.2e-5
+        # q | k of the fused projection in ONE launch (weight2) == the two separate launches
+        qk = torch.randn(M, 2 * d, device=dev, generator=g).to(bf16)
+        w2 = torch.randn(d, device=dev, generator=g)
+        sep = torch.cat([ops.rmsnorm_rope(qk[:, :d], w, rope=rope, head_dim=hd, tokens_per_batch=N, eps=1e-6),
+                         ops.rmsnorm_rope(qk[:, d:], w2, rope=rope, head_dim=hd, tokens_per_batch=N, eps=1e-6)], 1)
+        both = qk.clone()
+        ops.rmsnorm_rope(both, w, out=both, rope=rope, head_dim=hd, tokens_per_batch=N, eps=1e-6, weight2=w2)
+        assert torch.equal(both, sep)
 
 
 @pytest.mark.parametrize("spread", [0.03, 0.25], ids=["7_points_per_voxel", "1_point_per_voxel"])

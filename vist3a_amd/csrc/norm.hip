@@ -130,13 +130,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
 struct RmsP {
   const char* x; char* y;
   const float* w;       // [d]
+  const float* w2;      // second column block's weight (blockIdx.y = 1), or null
   const float* rope;    // [ntok][hd/2][2] (cos, sin) or null
   int M, d, ldx, ldy, hd, tokens_per_batch;
   float eps;
 };
 
 template <int CPL>
-__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const RmsP p) {
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const RmsP pin) {
+  RmsP p = pin;
+  if (blockIdx.y) { p.x += (size_t)p.d * 2; p.y += (size_t)p.d * 2; p.w = p.w2; }   // the k half of a fused q|k projection
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.M) return;
@@ -324,7 +327,8 @@ extern "C" int v3a_rmsnorm_rope(const v3a_rmsnorm_rope_args* a, void* stream) {
   p.hd = a->head_dim > 0 ? a->head_dim : a->d;
   p.tokens_per_batch = a->tokens_per_batch > 0 ? a->tokens_per_batch : a->M;
   p.eps = a->eps;
-  const dim3 grid((a->M + 3) / 4);
+  p.w2 = a->weight2;
+  const dim3 grid((a->M + 3) / 4, a->weight2 ? 2 : 1);
   DISPATCH_CPL(rmsnorm_rope_kernel, p, a->d, grid, stream);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }

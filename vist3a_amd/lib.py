@@ -138,6 +138,7 @@ class RmsNormRopeArgs(C.Structure):
         ("M", C.c_int), ("d", C.c_int), ("ldx", C.c_int), ("ldy", C.c_int),
         ("head_dim", C.c_int), ("tokens_per_batch", C.c_int),
         ("eps", C.c_float),
+        ("weight2", C.c_void_p),
     ]
 
 

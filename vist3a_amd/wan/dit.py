@@ -354,8 +354,7 @@ class WanDiT:
                 else:
                     for bi in range(B):
                         ops.gemm(b["wv"], ws.n[bi * N:(bi + 1) * N], b["bv"], out=ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True)
-                ops.rmsnorm_rope(q, b["nq"], out=q, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps)
-                ops.rmsnorm_rope(k, b["nk"], out=k, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps)
+                ops.rmsnorm_rope(ws.qk, b["nq"], out=ws.qk, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps, weight2=b["nk"])
                 if self.attn_dtype == "fp8":
                     if ws.qk8 is None:
                         ws.qk8 = torch.empty(ws.qk.shape, device=ws.qk.device, dtype=torch.uint8)
