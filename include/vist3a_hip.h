@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 12) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 13) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -217,6 +217,8 @@ typedef struct {
   float eps;
   const float* weight2;       /* non-NULL: a SECOND column block x[:, d:2d] -> y[:, d:2d] normalised with weight2 in the same launch
                                * (q and k of the fused q|k projection: one launch instead of two) */
+  float y_fp8_scale;          /* > 0: y is e4m3 BYTES [M, ldy] (ldy in bytes) holding e4m3(bf16(result) / y_fp8_scale), the operand format of
+                               * v3a_attention_fwd_fp8 (= this call followed by v3a_quantize_fp8, bit for bit, in one pass); y != x */
 } v3a_rmsnorm_rope_args;
 int v3a_rmsnorm_rope(const v3a_rmsnorm_rope_args* args, void* stream);
 

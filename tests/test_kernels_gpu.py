@@ -445,6 +445,10 @@ def test_norm_kernels_production_shapes(hip_lib, parity):
         both = qk.clone()
         ops.rmsnorm_rope(both, w, out=both, rope=rope, head_dim=hd, tokens_per_batch=N, eps=1e-6, weight2=w2)
         assert torch.equal(both, sep)
+        # ... and the e4m3 operand form (fp8 attention): == the bf16 result pushed through v3a_quantize_fp8
+        q8 = torch.empty(M, 2 * d, device=dev, dtype=torch.uint8)
+        ops.rmsnorm_rope(qk, w, out=q8, rope=rope, head_dim=hd, tokens_per_batch=N, eps=1e-6, weight2=w2, fp8_scale=0.5)
+        assert torch.equal(q8, ops.quantize_fp8(sep, 0.5))
 
 
 @pytest.mark.parametrize("spread", [0.03, 0.25], ids=["7_points_per_voxel", "1_point_per_voxel"])

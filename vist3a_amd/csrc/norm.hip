@@ -134,12 +134,13 @@ struct RmsP {
   const float* rope;    // [ntok][hd/2][2] (cos, sin) or null
   int M, d, ldx, ldy, hd, tokens_per_batch;
   float eps;
+  float f8_inv_scale;   // > 0: y is e4m3 BYTES [M][ldy], value = e4m3(clamp(bf16(result) * f8_inv_scale)) (operands of the fp8 attention)
 };
 
-template <int CPL>
+template <int CPL, bool F8OUT = false>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const RmsP pin) {
   RmsP p = pin;
-  if (blockIdx.y) { p.x += (size_t)p.d * 2; p.y += (size_t)p.d * 2; p.w = p.w2; }   // the k half of a fused q|k projection
+  if (blockIdx.y) { p.x += (size_t)p.d * 2; p.y += (size_t)p.d * (F8OUT ? 1 : 2); p.w = p.w2; }   // the k half of a fused q|k projection
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.M) return;
@@ -180,7 +181,18 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const RmsP pin) {
         o[2 * e + 1] = x0 * si + x1 * co;
       }
     }
-    *(u32x4*)(p.y + ((size_t)row * p.ldy + c * 8) * 2) = pack_bf16x8(o);
+    if constexpr (F8OUT) {   // same two roundings as rmsnorm_rope -> bf16 -> v3a_quantize_fp8
+      float f[8];
+      unpack_bf16x8(pack_bf16x8(o), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e] * p.f8_inv_scale, -448.f), 448.f);
+      u32x2 q;
+      q[0] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false), true);
+      q[1] = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false), true);
+      *(u32x2*)(p.y + (size_t)row * p.ldy + c * 8) = q;
+    } else {
+      *(u32x4*)(p.y + ((size_t)row * p.ldy + c * 8) * 2) = pack_bf16x8(o);
+    }
   }
 }
 
@@ -328,7 +340,16 @@ extern "C" int v3a_rmsnorm_rope(const v3a_rmsnorm_rope_args* a, void* stream) {
   p.tokens_per_batch = a->tokens_per_batch > 0 ? a->tokens_per_batch : a->M;
   p.eps = a->eps;
   p.w2 = a->weight2;
+  p.f8_inv_scale = a->y_fp8_scale > 0.f ? 1.0f / a->y_fp8_scale : 0.f;
+  if (a->y_fp8_scale < 0.f || (a->y_fp8_scale > 0.f && a->y == a->x)) return V3A_ERR_ARG;   // (bytes cannot overwrite the bf16 input in place)
   const dim3 grid((a->M + 3) / 4, a->weight2 ? 2 : 1);
+  if (p.f8_inv_scale > 0.f) {   // (its own instantiations: the extra live registers would cost the bf16 kernels a wave per SIMD)
+    const int cpl = (a->d / 8 + 63) / 64;
+    if (cpl <= 3) hipLaunchKernelGGL((rmsnorm_rope_kernel<3, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (cpl <= 10) hipLaunchKernelGGL((rmsnorm_rope_kernel<10, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else return V3A_ERR_SHAPE;
+    return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+  }
   DISPATCH_CPL(rmsnorm_rope_kernel, p, a->d, grid, stream);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }

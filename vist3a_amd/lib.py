@@ -139,6 +139,7 @@ class RmsNormRopeArgs(C.Structure):
         ("head_dim", C.c_int), ("tokens_per_batch", C.c_int),
         ("eps", C.c_float),
         ("weight2", C.c_void_p),
+        ("y_fp8_scale", C.c_float),
     ]
 
 

@@ -424,9 +424,10 @@ def layernorm(
 def rmsnorm_rope(
     x: torch.Tensor, weight: torch.Tensor, *, out: Optional[torch.Tensor] = None,
     rope: Optional[torch.Tensor] = None, head_dim: int = 0, tokens_per_batch: int = 0, eps: float = 1e-6,
-    weight2: Optional[torch.Tensor] = None,
+    weight2: Optional[torch.Tensor] = None, fp8_scale: float = 0.0,
 ) -> torch.Tensor:
-    """weight2: x is [M, 2d] = [q | k] of a fused projection; both halves are normalised (q with weight, k with weight2) in one launch."""
+    """weight2: x is [M, 2d] = [q | k] of a fused projection; both halves are normalised (q with weight, k with weight2) in one launch.
+    fp8_scale > 0: `out` (required, uint8, same shape) receives e4m3(bf16(result) / fp8_scale) - the fp8 attention's operand format."""
     _chk2d(x, "x", (bf16,))
     M, d = x.shape
     if weight2 is not None:
@@ -434,8 +435,8 @@ def rmsnorm_rope(
             raise ValueError("weight2 must be contiguous f32 [d] for x [M, 2d]")
         d //= 2
     if out is None:
-        out = torch.empty(tuple(x.shape), device=x.device, dtype=bf16)
-    _chk2d(out, "out", (bf16,))
+        out = torch.empty(tuple(x.shape), device=x.device, dtype=torch.uint8 if fp8_scale > 0 else bf16)
+    _chk2d(out, "out", (torch.uint8, torch.float8_e4m3fn) if fp8_scale > 0 else (bf16,))
     if tuple(out.shape) != tuple(x.shape):
         raise ValueError("out must have the shape of x")
     if weight.dtype != f32 or not weight.is_contiguous() or weight.numel() != d:
@@ -444,7 +445,7 @@ def rmsnorm_rope(
         raise ValueError("rope table must be contiguous f32 [tokens, head_dim/2, 2]")
     args = L.RmsNormRopeArgs(
         _ptr(x), _ptr(out), _ptr(weight), _ptr(rope), M, d, x.stride(0), out.stride(0),
-        head_dim, tokens_per_batch, eps, _ptr(weight2),
+        head_dim, tokens_per_batch, eps, _ptr(weight2), float(fp8_scale),
     )
     L.check(L.load().v3a_rmsnorm_rope(C.byref(args), _stream()), "v3a_rmsnorm_rope")
     return out

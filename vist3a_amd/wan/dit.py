@@ -354,18 +354,23 @@ class WanDiT:
                 else:
                     for bi in range(B):
                         ops.gemm(b["wv"], ws.n[bi * N:(bi + 1) * N], b["bv"], out=ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True)
-                ops.rmsnorm_rope(ws.qk, b["nq"], out=ws.qk, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps, weight2=b["nk"])
                 if self.attn_dtype == "fp8":
                     if ws.qk8 is None:
                         ws.qk8 = torch.empty(ws.qk.shape, device=ws.qk.device, dtype=torch.uint8)
                         ws.vt8 = torch.zeros(ws.vt.shape, device=ws.vt.device, dtype=torch.uint8)
                     qs, ksc, vs = self.fp8_scales
-                    ops.quantize_fp8(q, qs, out=ws.qk8[:, :d])
-                    ops.quantize_fp8(k, ksc, out=ws.qk8[:, d:])
+                    if qs == ksc:   # RMSNorm + RoPE emit the e4m3 operands themselves (= bf16 result -> v3a_quantize_fp8, in one pass)
+                        ops.rmsnorm_rope(ws.qk, b["nq"], out=ws.qk8, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps, weight2=b["nk"],
+                                         fp8_scale=qs)
+                    else:
+                        ops.rmsnorm_rope(ws.qk, b["nq"], out=ws.qk, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps, weight2=b["nk"])
+                        ops.quantize_fp8(q, qs, out=ws.qk8[:, :d])
+                        ops.quantize_fp8(k, ksc, out=ws.qk8[:, d:])
                     ops.quantize_fp8(ws.vt, vs, out=ws.vt8)
                     ops.attention_fp8(ws.qk8[:, :d], ws.qk8[:, d:], ws.vt8, ws.ao, B=B, H=H, Nq=N, Nk=N, q_batch_stride=N * 2 * d,
                                       k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d, q_scale=qs, k_scale=ksc, v_scale=vs)
                 else:
+                    ops.rmsnorm_rope(ws.qk, b["nq"], out=ws.qk, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps, weight2=b["nk"])
                     ops.attention(q, k, ws.vt, ws.ao, B=B, H=H, Nq=N, Nk=N, D=hd, q_batch_stride=N * 2 * d,
                                   k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d)
             else:
