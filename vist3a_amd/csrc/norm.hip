@@ -35,25 +35,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
   const int nch = p.d >> 3;
   float v[CPL][8];
   float sum = 0.f;
+  // All of the row's loads are issued back to back, branch-free (chunks past the row end read the last chunk and are zeroed):
+  // under a per-lane `if (c < nch)` hipcc wraps every load in exec-mask control flow and waits for each one before issuing the next -
+  // three serial memory round trips per row at d = 1536.
+  if (p.x_f32) {   // (wave-uniform)
+    f32x4 ra[CPL], rb[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      const float* xp = (const float*)p.x + row * p.ldx + min(lane + i * 64, nch - 1) * 8;
+      ra[i] = *(const f32x4*)xp; rb[i] = *(const f32x4*)(xp + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[i][e] = ra[i][e]; v[i][4 + e] = rb[i][e]; }
+  } else {
+    u32x4 raw[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) raw[i] = *(const u32x4*)(p.x + (row * p.ldx + min(lane + i * 64, nch - 1) * 8) * 2);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) unpack_bf16x8(raw[i], v[i]);
+  }
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
-    const int c = lane + i * 64;
-    if (c < nch) {
-      if (p.x_f32) {
-        const float* xp = (const float*)p.x + row * p.ldx + c * 8;
-        const f32x4 a = *(const f32x4*)xp, bq = *(const f32x4*)(xp + 4);
+    const bool live = lane + i * 64 < nch;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = bq[e]; }
-      } else {
-        const u32x4 raw = *(const u32x4*)(p.x + (row * p.ldx + c * 8) * 2);
-        unpack_bf16x8(raw, v[i]);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sum += v[i][e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-    }
+    for (int e = 0; e < 8; ++e) { v[i][e] = live ? v[i][e] : 0.f; sum += v[i][e]; }
   }
   const float mean = p.rms ? 0.f : wave_sum(sum) / (float)p.d;
   float sq = 0.f;
@@ -147,14 +154,16 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const RmsP pin) {
   const int nch = p.d >> 3;
   float v[CPL][8];
   float sq = 0.f;
+  {   // branch-free, all loads in flight together (see layernorm_kernel)
+    u32x4 raw[CPL];
 #pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    const int c = lane + i * 64;
-    if (c < nch) {
-      const u32x4 raw = *(const u32x4*)(p.x + ((size_t)row * p.ldx + c * 8) * 2);
-      unpack_bf16x8(raw, v[i]);
+    for (int i = 0; i < CPL; ++i) raw[i] = *(const u32x4*)(p.x + ((size_t)row * p.ldx + min(lane + i * 64, nch - 1) * 8) * 2);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sq += v[i][e] * v[i][e];
+    for (int i = 0; i < CPL; ++i) {
+      unpack_bf16x8(raw[i], v[i]);
+      const bool live = lane + i * 64 < nch;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = live ? v[i][e] : 0.f; sq += v[i][e] * v[i][e]; }
     }
   }
   const float rs = rsqrtf(wave_sum(sq) / (float)p.d + p.eps);
