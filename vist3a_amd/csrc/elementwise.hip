@@ -247,39 +247,53 @@ struct LinP {
   const float* x; const float* w; const float* b; float* y; const float* res; const float* gamma;
   int M, N, K, ldx, ldy, ldr, act;
 };
-template <int MAXM>
+// One wave per NPW consecutive outputs: every x fragment fetched from L1/L2 is used against NPW weight rows (with one output
+// per wave the 13 activation loads per 16-byte weight load, not the weight stream, set the pace: 0.7 TB/s).  Per output the k-order of
+// the partial sums is unchanged.
+template <int MAXM, int NPW>
 __global__ __launch_bounds__(256) void linear_f32_kernel(const LinP p) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= p.N) return;
-  float acc[MAXM];
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW;
+  if (n0 >= p.N) return;
+  float acc[NPW][MAXM];
 #pragma unroll
-  for (int m = 0; m < MAXM; ++m) acc[m] = 0.f;
-  const float* wr = p.w + (size_t)n * p.K;
+  for (int j = 0; j < NPW; ++j)
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) acc[j][m] = 0.f;
+  const float* wr[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) wr[j] = p.w + (size_t)min(n0 + j, p.N - 1) * p.K;   // (rows past N are computed and dropped)
   for (int k = lane * 4; k < p.K; k += 256) {
-    const f32x4 wv = *(const f32x4*)(wr + k);
+    f32x4 wv[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) wv[j] = *(const f32x4*)(wr[j] + k);
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) {
       if (m < p.M) {
         const f32x4 xv = *(const f32x4*)(p.x + (size_t)m * p.ldx + k);
-        acc[m] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) acc[j][m] += wv[j][0] * xv[0] + wv[j][1] * xv[1] + wv[j][2] * xv[2] + wv[j][3] * xv[3];
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < MAXM; ++m) acc[m] = wave_sum(acc[m]);
-  float mine = 0.f;
+  for (int j = 0; j < NPW; ++j) {
+    const int n = n0 + j;
+    float mine = 0.f;
 #pragma unroll
-  for (int m = 0; m < MAXM; ++m)
-    if (lane == m) mine = acc[m];
-  if (lane < p.M) {
-    float v = mine + (p.b ? p.b[n] : 0.f);
-    if (p.act == V3A_ACT_GELU_ERF) v = gelu_erf(v);
-    else if (p.act == V3A_ACT_SILU) v = silu(v);
-    else if (p.act == V3A_ACT_RELU) v = fmaxf(v, 0.f);
-    if (p.gamma) v *= p.gamma[n];
-    if (p.res) v += p.res[(size_t)lane * p.ldr + n];
-    p.y[(size_t)lane * p.ldy + n] = v;
+    for (int m = 0; m < MAXM; ++m) {
+      const float t = wave_sum(acc[j][m]);
+      if (lane == m) mine = t;
+    }
+    if (n < p.N && lane < p.M) {
+      float v = mine + (p.b ? p.b[n] : 0.f);
+      if (p.act == V3A_ACT_GELU_ERF) v = gelu_erf(v);
+      else if (p.act == V3A_ACT_SILU) v = silu(v);
+      else if (p.act == V3A_ACT_RELU) v = fmaxf(v, 0.f);
+      if (p.gamma) v *= p.gamma[n];
+      if (p.res) v += p.res[(size_t)lane * p.ldr + n];
+      p.y[(size_t)lane * p.ldy + n] = v;
+    }
   }
 }
 
@@ -380,9 +394,8 @@ extern "C" int v3a_linear_f32(const float* x, const float* w, const float* bias,
   if (!x || !w || !y) return V3A_ERR_ARG;
   if (M <= 0 || M > 32 || N <= 0 || K <= 0 || K % 4 || ldx % 4) return V3A_ERR_SHAPE;
   LinP p{x, w, bias, y, residual, gamma, M, N, K, ldx, ldy, ldr, act};
-  const dim3 grid((N + 3) / 4);
-  if (M <= 16) hipLaunchKernelGGL(linear_f32_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(linear_f32_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (M <= 16) hipLaunchKernelGGL((linear_f32_kernel<16, 4>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((linear_f32_kernel<32, 2>), dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, p);
   return LAUNCH_OK();
 }
 
