@@ -322,7 +322,7 @@ class ReconEngine:
         dev = self.dev
         ext, K = pose_encoding_to_extri_intri(pose, (H, W))
         Rt = ext[:, :, :3].transpose(1, 2)
-        tinv = -(Rt @ ext[:, :, 3:])[..., 0]
+        tinv = -(Rt * ext[:, None, :, 3]).sum(-1)   # -R^T t, elementwise (a [S,3,3] @ [S,3,1] matmul would dispatch a BLAS kernel for 9 FMAs)
         cam = torch.cat([K[:, 0, 0:1], K[:, 1, 1:2], K[:, 0, 2:3], K[:, 1, 2:3], Rt.reshape(S, 9), tinv], 1).contiguous()
         R = L.ACT_RELU
         # depth head
