@@ -960,6 +960,9 @@ const TileEntry kTiles[] = {
     TILE_ENTRY(64, 128, 2, 2, 64, 2),   // 9
     TILE_ENTRY(128, 64, 2, 2, 64, 2),   // 10
     TILE_ENTRY(64, 64, 2, 2, 64, 2),    // 11
+    // 12: the VAE decoder's full-resolution 96 -> 96 channel convolutions (13 x 512 x 512 pixels): no padding of N to 128; two workgroups
+    //     per CU.  3.21 -> 2.84 ms per layer against 256x128 (256x96 and 2-wave forms measured 4.5 ms)
+    TILE_ENTRY(128, 96, 4, 1, 64, 2),
 #ifdef V3A_GEMM_ABL
     PP_ABL(4, true, 7, 1), PP_ABL(4, true, 7, 2), PP_ABL(4, true, 7, 3), PP_ABL(4, true, 7, 4), PP_ABL(4, true, 7, 5), PP_ABL(4, true, 7, 6),
     PP_ABL(3, true, 5, 1), PP_ABL(3, true, 5, 3), PP_ABL(3, true, 5, 4), PP_ABL(3, true, 5, 16), PP_ABL(3, true, 5, 32), PP_ABL(3, true, 5, 64), PP_ABL(3, true, 5, 128), PP_ABL(3, true, 5, 192),
@@ -981,6 +984,7 @@ constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
 int pick_tile(int M, int N, bool conv = false, int mult = 1) {
   // Launch time ~ (tiles the busiest CU runs one after another or side by side) x (tile area incl. padding waste) / (measured
   // efficiency of the tile family; fitted to tools/gemm_sweep.py over the production and the sequence-parallel shard shapes).
+  if (conv && N <= 96 && N > 64 && M >= 256 * 256) return 12;   // (measured: tools/vae_time.py)
   double best = 1e30;
   int bi = 5;
   for (int i : kAutoList) {
