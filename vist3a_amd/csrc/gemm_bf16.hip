@@ -984,12 +984,15 @@ constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
 int pick_tile(int M, int N, bool conv = false, int mult = 1) {
   // Launch time ~ (tiles the busiest CU runs one after another or side by side) x (tile area incl. padding waste) / (measured
   // efficiency of the tile family; fitted to tools/gemm_sweep.py over the production and the sequence-parallel shard shapes).
-  if (conv && N <= 96 && N > 64 && M >= 256 * 256) return 12;   // (measured: tools/vae_time.py)
+  // convolutions (fitted to tools/conv_sweep_scene.py): narrow outputs take the narrow tiles - no N padded to 128 / 192 -
+  // and only small feature maps (the DPT pyramid's 16^2 / 32^2 levels) may use the small tiles of the cost model below
+  if (conv && N <= 64 && M >= 256 * 256) return 10;
+  if (conv && N <= 96 && N > 64 && M >= 256 * 256) return 12;
   double best = 1e30;
   int bi = 5;
   for (int i : kAutoList) {
     const TileEntry& e = kTiles[i];
-    if (conv && (!e.conv_fn || i >= 9)) continue;   // (the small tiles were fitted on GEMM shards only: convolutions keep their tiles)
+    if (conv && (!e.conv_fn || (i >= 9 && M > 16384))) continue;
     long tm = (M + e.BM - 1) / e.BM, tn = (N + e.BN - 1) / e.BN;
     long tiles = tm * tn * mult;   // (mult: split-K slices launched side by side)
     const bool pp = i >= 6 && i <= 8;
