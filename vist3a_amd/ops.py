@@ -37,8 +37,15 @@ class GemmProbe:
     """Optional HIP-event instrumentation of the GEMM launches that resolve to one tile configuration (= one kernel symbol):
     accumulates algorithmic FLOPs and event pairs so bench.py can report that kernel's live roofline numbers."""
 
-    def __init__(self, tile: int, fp8: bool = False):
+    def __init__(self, tile: int, fp8: bool = False, stride: int = 1):
+        """stride > 1: only every stride-th matching launch is bracketed by events (an event pair costs ~5 us of stream time; pick a
+        stride coprime to the period of the launch sequence so that every shape is sampled)"""
         self.tile, self.fp8, self.flops, self.events, self.active = tile, fp8, 0.0, [], False
+        self.stride, self.seen = max(1, int(stride)), 0
+
+    def take(self) -> bool:
+        self.seen += 1
+        return self.seen % self.stride == 0
 
     def summary(self):
         torch.cuda.synchronize()
@@ -154,7 +161,7 @@ def gemm(
                 raise ValueError(f"{nm} must be contiguous f32 of length {n}")
         fargs = L.GemmFp8Args(args, _ptr(a_scale), _ptr(w_scale))
         pr = _probe
-        timed = pr is not None and pr.active and pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_fp8_pick_tile(M, N)) == pr.tile
+        timed = pr is not None and pr.active and pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_fp8_pick_tile(M, N)) == pr.tile and pr.take()
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -165,7 +172,7 @@ def gemm(
             pr.flops += 2.0 * M * N * K
         return out
     pr = _probe
-    if pr is not None and pr.active and not pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile(M, N)) == pr.tile:
+    if pr is not None and pr.active and not pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile(M, N)) == pr.tile and pr.take():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")
