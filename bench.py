@@ -152,10 +152,7 @@ def main():
     lib.load()
     cfg = WAN_14B if a.model == "14b" else WAN_1_3B
     model = Text23DGS.synthetic(cfg, seed=0, device=dev)
-    if coop_requested(a, world) and a.dtype == "fp8-attn":
-        raise SystemExit("the e4m3 attention kernel covers the single-GPU path; --parallel scene takes --dtype bf16 or fp8 (e4m3 GEMMs)")
-    # sequence-parallel shards run the bf16 flash kernel over the gathered slabs (key-split); their GEMMs take the e4m3 mode unchanged
-    model.transformer.attn_dtype = "bf16" if (a.dtype == "bf16" or coop_requested(a, world)) else "fp8"
+    model.transformer.attn_dtype = "bf16" if a.dtype == "bf16" else "fp8"   # (sharded runs: e4m3 K | V^T slabs are what is all-gathered)
     if a.dtype == "fp8":
         model.transformer.enable_fp8_gemm()
     pe, ne = synthetic_text_embeddings(dev)
@@ -257,8 +254,7 @@ def main():
             "value": (1 if coop else world) * a.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if coop else "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp8-attn": "fp8 (e4m3 self-attention operands; bf16 GEMMs)",
-                      "fp8": ("fp8 (e4m3 block projection / FFN GEMM operands, fp32 accumulation; bf16 attention over the gathered slabs)" if coop else
-                              "fp8 (e4m3 self-attention and block projection / FFN GEMM operands, fp32 accumulation; bf16 elsewhere)")}[a.dtype],
+                      "fp8": "fp8 (e4m3 self-attention and block projection / FFN GEMM operands, fp32 accumulation; bf16 elsewhere)"}[a.dtype],
             "data": "synthetic (seeded random weights of production shapes, synthetic text embeddings)",
             "config": {"workload": f"Wan-{'14B' if a.model == '14b' else '1.3B'} stitched, {a.denoise_steps}-step CFG denoise (batch-2 cond/uncond), {a.num_frames} views @512, "
                                    "VAE decode, 448^2 AnySplat enc_blocks_2 reconstruction with voxel fusion; "

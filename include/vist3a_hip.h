@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 13) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 14) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -181,6 +181,10 @@ typedef struct {
   int B, H, Nq, Nk, D;
   float scale;                      /* softmax scale, normally D^-0.5 */
   float q_scale, k_scale, v_scale;  /* per-tensor quantisation scales */
+  int kv_seg;               /* as in v3a_attn_args: K / V^T read in place from per-rank slabs; k_seg_stride / vt_seg_stride in BYTES */
+  long k_seg_stride, vt_seg_stride;
+  int kv_split;             /* as in v3a_attn_args (workspace: v3a_attention_split_workspace_bytes(B, H, Nq, 128, kv_split)) */
+  void* workspace;
 } v3a_attn_fp8_args;
 int v3a_attention_fwd_fp8(const v3a_attn_fp8_args* args, void* stream);
 int v3a_quantize_fp8(const void* x, void* y, long rows, int cols, int ldx, int ldy, float scale, void* stream);

@@ -383,6 +383,10 @@ def test_wan14b_width_fp8_gemm_matches_e4m3_oracle(hip_lib, parity):
     tw = ThreadWorld(2)
     outs = tw.run(lambda r: model(lat.cuda(), t.cuda(), text.cuda(), sp=tw.group(r))[0].clone())
     assert all(torch.equal(o, outg) for o in outs)
+    # ... and with the e4m3 attention too: the ranks all-gather e4m3 K | V^T slabs and the fp8 flash kernel walks them in place
+    model.attn_dtype = "fp8"
+    outs = tw.run(lambda r: model(lat.cuda(), t.cuda(), text.cuda(), sp=tw.group(r))[0].clone())
+    assert all(torch.equal(o, outga) for o in outs)
 
 
 @pytest.mark.parametrize("P", [4, 8])

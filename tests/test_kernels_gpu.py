@@ -523,6 +523,38 @@ def test_attention_fp8_matches_e4m3_emulation(hip_lib, parity, B, H, Nq, Nk):
     assert r_exact < 6e-2, r_exact      # what e4m3 operands cost (3 mantissa bits)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,S", [(1, 40, 512, 4096, 5), (2, 4, 300, 1000, 3)])
+def test_attention_fp8_key_split_and_slabs(hip_lib, parity, B, H, Nq, Nk, S):
+    """The e4m3 kernel on a sequence-parallel shard's launch: kv_split merges partial softmaxes (deterministic; within the e4m3 P
+    rounding of the unsplit kernel - a split changes which running maximum P is rounded against), and kv_seg reads K / V^T from
+    per-rank slabs bit-identically to the contiguous layout."""
+    from vist3a_amd import ops
+    D = 128
+    g = torch.Generator(device=dev).manual_seed(S + Nk)
+    q, k, v, vt, nkp = _fp8_inputs(B, H, Nq, Nk, g)
+    q8, k8, vt8 = ops.quantize_fp8(q.view(B * Nq, H * D)), ops.quantize_fp8(k.view(B * Nk, H * D)), ops.quantize_fp8(vt)
+    kw = dict(B=B, H=H, Nq=Nq, Nk=Nk, q_batch_stride=Nq * H * D, k_batch_stride=Nk * H * D, vt_batch_stride=nkp, o_batch_stride=Nq * H * D)
+    run = lambda **e: ops.attention_fp8(q8, k8, vt8, torch.empty(B * Nq, H * D, device=dev, dtype=bf16), **kw, **e)
+    one, a, b = run(), run(kv_split=S), run(kv_split=S)
+    exact = _attn_ref(q, k, v, B, H, D).reshape(B * Nq, H * D)
+    r, re1, reS = relerr(a, one), relerr(one, exact), relerr(a, exact)
+    parity("attention_fp8_key_split", B=B, H=H, Nq=Nq, Nk=Nk, S=S, rel_vs_unsplit=r, unsplit_vs_fp32=re1, split_vs_fp32=reS)
+    # P is rounded to e4m3 against the running maximum of ITS key range, so split and unsplit round differently: each stays at the
+    # e4m3 mode's distance from exact attention (5e-2), and they differ from each other by about the same
+    assert torch.equal(a, b) and reS < 6e-2 and reS < 1.2 * re1 and r < 6e-2, (r, re1, reS)
+    if Nk % 128 == 0 and B == 1:   # two slabs of Nk / 2 keys each, laid out like the all-gather buffer: [K_0 | VT_0][K_1 | VT_1]
+        seg, d = Nk // 2, H * D
+        slab = torch.empty(2, 2 * seg * d, device=dev, dtype=torch.uint8)
+        for r_ in range(2):
+            slab[r_, :seg * d] = k8[r_ * seg:(r_ + 1) * seg].reshape(-1)
+            slab[r_, seg * d:] = vt8[:, r_ * seg:(r_ + 1) * seg].reshape(-1)
+        o = torch.empty(B * Nq, d, device=dev, dtype=bf16)
+        ops.attention_fp8(q8, slab[0, :seg * d].view(seg, d), slab[0, seg * d:].view(d, seg), o, B=B, H=H, Nq=Nq, Nk=Nk, q_batch_stride=Nq * d,
+                          k_batch_stride=seg * d, vt_batch_stride=seg, o_batch_stride=Nq * d, kv_seg=seg, k_seg_stride=2 * seg * d,
+                          vt_seg_stride=2 * seg * d)
+        assert torch.equal(o, one)
+
+
 def test_attention_fp8_production_shape_and_speed(hip_lib, parity):
     """Wan-14B self-attention launch (B=1 per CFG branch, 40 heads, 4096 x 4096): finite, deterministic, close to bf16 attention."""
     from vist3a_amd import ops

@@ -40,8 +40,9 @@ def timed(fn, n=5):
 if __name__ == "__main__":
     cfg = WAN_14B if "14b" in sys.argv[1:] else WAN_1_3B
     m = WanDiT(cfg, random_dit_state_dict(cfg, seed=0, device="cuda"))
-    if "fp8" in sys.argv[1:]:   # e4m3 block GEMMs (the sharded path keeps the bf16 key-split attention)
+    if "fp8" in sys.argv[1:]:   # config #4's precision mode: e4m3 block GEMMs and e4m3 attention over e4m3 K | V^T slabs
         m.enable_fp8_gemm()
+        m.attn_dtype = "fp8"
     text = torch.zeros(1, 512, 4096, device="cuda")
     text[0, :64] = torch.randn(64, 4096, device="cuda") * 0.1
     t = torch.tensor([900], device="cuda")

@@ -47,6 +47,7 @@ struct AttnP {
   long k_seg, vt_seg;             //      key kk of a batch item is row (kk % kv_seg) of segment kk / kv_seg, segments k_seg / vt_seg elements apart
   int kv_split, B;                // > 1: the key tiles are divided among kv_split workgroups per query block, each writing an
   float* ws_o; float* ws_ml;      //      UNNORMALISED fp32 partial O [S][B][Nq][H*D] and its (reference, sum) [S][B][Nq][H][2]
+  float out_mul;                  // combine: factor on the merged result (1 for bf16; 256 * v_scale for the e4m3 kernel's units)
 };
 
 // One source, two staging schedules of the same arithmetic (V1):
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnP p) {
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] += w * po[e];
   }
-  const float inv = 1.0f / L;
+  const float inv = p.out_mul / L;
   char* o = p.o + ((size_t)b * p.o_bs + (size_t)q * p.ldo + (size_t)h * D + lane * E) * 2;
   if constexpr (E == 2) *(unsigned*)o = pack_bf16x2(acc[0] * inv, acc[1] * inv);
   else *(unsigned short*)o = (unsigned short)(pack_bf16x2(acc[0] * inv, 0.f) & 0xffffu);
@@ -409,12 +410,26 @@ int launch_attn(const AttnP& p, int B, void* stream) {
   hipLaunchKernelGGL(fn, dim3((unsigned)(nqb * B * p.H * S)), dim3(NW * 64), LDS, (hipStream_t)stream, p);
   if (S > 1) {
     const long waves = (long)B * p.Nq * p.H;
-    hipLaunchKernelGGL(attn_combine_kernel<D>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    AttnP pc = p;
+    pc.out_mul = 1.0f;
+    hipLaunchKernelGGL(attn_combine_kernel<D>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pc);
   }
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
 }  // namespace
+
+// shared with attention_fp8.hip
+int v3a_attn_combine_launch(const float* ws_o, const float* ws_ml, void* o, long o_bs, int ldo, int B, int Nq, int H, int D, int S,
+                            float scale_log2e, float out_mul, void* stream) {
+  if (D != 128) return V3A_ERR_SHAPE;
+  AttnP p = {};
+  p.ws_o = const_cast<float*>(ws_o); p.ws_ml = const_cast<float*>(ws_ml); p.o = (char*)o; p.o_bs = o_bs; p.ldo = ldo;
+  p.B = B; p.Nq = Nq; p.H = H; p.kv_split = S; p.scale_log2e = scale_log2e; p.out_mul = out_mul;
+  const long waves = (long)B * Nq * H;
+  hipLaunchKernelGGL(attn_combine_kernel<128>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}
 
 extern "C" size_t v3a_attention_split_workspace_bytes(int B, int H, int Nq, int D, int kv_split) {
   if (B <= 0 || H <= 0 || Nq <= 0 || D <= 0 || kv_split <= 1) return 0;

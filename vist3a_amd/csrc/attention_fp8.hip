@@ -19,6 +19,10 @@
 #include "common.h"
 #include "../../include/vist3a_hip.h"
 
+// defined in attention.hip: merges key-split partial softmaxes (out = out_mul * sum_s w_s O_s / sum_s w_s l_s) into bf16 rows
+int v3a_attn_combine_launch(const float* ws_o, const float* ws_ml, void* o, long o_bs, int ldo, int B, int Nq, int H, int D, int S,
+                            float scale_log2e, float out_mul, void* stream);
+
 namespace {
 
 
@@ -29,6 +33,10 @@ struct Attn8P {
   int H, Nq, Nk;
   float scale_log2e;              // softmax scale * q_scale * k_scale * log2(e)
   float out_scale;                // v_scale
+  int kv_seg;                     // > 0: keys live in per-rank slabs of kv_seg keys (see attention.hip), k_seg / vt_seg BYTES apart
+  long k_seg, vt_seg;
+  int kv_split, B;                // > 1: key tiles divided among kv_split workgroups, partials merged by v3a_attn_combine_launch
+  float* ws_o; float* ws_ml;
 };
 
 constexpr int D = 128, NW = 4, KV = 64;
@@ -50,7 +58,9 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_fp8_kernel(const Attn8P p
   const int hi = lane >> 5, l31 = lane & 31;
 
   const int nqb = (p.Nq + NW * 32 - 1) / (NW * 32);
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int S = p.kv_split > 1 ? p.kv_split : 1;
+  const int bid0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid0 % S, bid = bid0 / S;
   const int bh = bid / nqb, qb = bid % nqb;
   const int b = bh / p.H, h = bh % p.H;
   const int q0 = qb * (NW * 32) + wave * 32;
@@ -86,16 +96,19 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_fp8_kernel(const Attn8P p
     vp[j] = Vb + (size_t)d * p.ldvt + (size_t)((lane & 3) ^ ((d >> 2) & 3)) * 16;
   }
   auto stage_k = [&](int s, int kt) {
+    // (slabs: a 64-key tile lies inside one segment; its base moves by k_seg - kv_seg * ldk bytes per segment crossed)
+    const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.k_seg - (long)p.kv_seg * p.ldk) : 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int row = kt * KV + krow[j];
       row = row < p.Nk ? row : p.Nk - 1;
-      glds16(kp[j] + (size_t)row * p.ldk, smem + s * KTILE + (j * NW + wave) * 1024);
+      glds16(kp[j] + (size_t)row * p.ldk + so, smem + s * KTILE + (j * NW + wave) * 1024);
     }
   };
   auto stage_v = [&](int kt) {
+    const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.vt_seg - p.kv_seg) : 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) glds16(vp[j] + (size_t)kt * KV, smem + 2 * KTILE + (j * NW + wave) * 1024);
+    for (int j = 0; j < 2; ++j) glds16(vp[j] + (size_t)kt * KV + so, smem + 2 * KTILE + (j * NW + wave) * 1024);
   };
   // ---- fragment offsets ----
   // K (A operand): MFMA row i = l31 <-> key pi(i) of the 32-key sub-tile; k-step s: chunks 4 s + 2 hi, + 1
@@ -119,14 +132,15 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_fp8_kernel(const Attn8P p
   float m_run = -1e30f, l_run = 0.f;
   const float c = p.scale_log2e;
   const int nkt = (p.Nk + KV - 1) / KV;
-  stage_k(0, 0);
+  const int kt0 = (int)((long)split * nkt / S), kt1 = (int)((long)(split + 1) * nkt / S);
+  stage_k(0, kt0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
     stage_v(kt);
-    if (kt + 1 < nkt) stage_k(cur ^ 1, kt + 1);
+    if (kt + 1 < kt1) stage_k(cur ^ 1, kt + 1);
     const char* sK = smem + cur * KTILE;
     const char* sV = smem + 2 * KTILE;
     f32x16 s[2];
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_fp8_kernel(const Attn8P p
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
     }
-    if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // V^T pieces were issued before the next K pieces
+    if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // V^T pieces were issued before the next K pieces
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -197,6 +211,27 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_fp8_kernel(const Attn8P p
 
   // ---- finish ----
   l_run += __shfl_xor(l_run, 32, 64);
+  if (S > 1) {   // unnormalised partial + (reference, sum in units of 2^8): merged by attn_combine_kernel with out_mul = 256 v_scale
+    const int qr = q0 + l31;
+    if (qr < p.Nq) {
+      const size_t row = ((size_t)split * p.B + b) * p.Nq + qr;
+      float* po = p.ws_o + (row * p.H + h) * D;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = oacc[i][g * 4 + e];
+          *(f32x4*)(po + i * 32 + g * 8 + hi * 4) = v;
+        }
+      if (hi == 0) {
+        float* pm = p.ws_ml + (row * p.H + h) * 2;
+        pm[0] = m_run; pm[1] = l_run;
+      }
+    }
+    return;
+  }
   const float inv = p.out_scale * 256.0f / l_run;   // l is in units of 2^8 while the block scale already removed P's 2^8
   char* reg = smem + wave * (32 * OPITCH);
 #pragma unroll
@@ -337,6 +372,15 @@ extern "C" int v3a_attention_fwd_fp8(const v3a_attn_fp8_args* a, void* stream) {
   p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
   p.scale_log2e = a->scale * a->q_scale * a->k_scale * 1.4426950408889634f;
   p.out_scale = a->v_scale;
+  p.B = a->B; p.kv_split = a->kv_split > 1 ? a->kv_split : 1;
+  p.kv_seg = a->kv_seg; p.k_seg = a->k_seg_stride; p.vt_seg = a->vt_seg_stride;
+  if (a->kv_seg < 0 || a->kv_split < 0) return V3A_ERR_ARG;
+  if (a->kv_seg > 0 && (a->kv_seg % 64 || a->Nk % a->kv_seg || a->k_seg_stride % 16 || a->vt_seg_stride % 16)) return V3A_ERR_SHAPE;
+  if (p.kv_split > 1) {
+    if (!a->workspace || p.kv_split > (a->Nk + 63) / 64) return V3A_ERR_ARG;
+    p.ws_o = (float*)a->workspace;
+    p.ws_ml = p.ws_o + (size_t)p.kv_split * a->B * a->Nq * a->H * D;
+  }
   constexpr int OBYTES = NW * 32 * (D * 2 + 8);
   constexpr int LDS = (2 * KTILE + VTILE > OBYTES) ? 2 * KTILE + VTILE : OBYTES;
   static bool attr = false;
@@ -345,6 +389,10 @@ extern "C" int v3a_attention_fwd_fp8(const v3a_attn_fp8_args* a, void* stream) {
     attr = true;
   }
   const int nqb = (a->Nq + NW * 32 - 1) / (NW * 32);
-  hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3((unsigned)(nqb * a->B * a->H)), dim3(NW * 64), LDS, (hipStream_t)stream, p);
-  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+  hipLaunchKernelGGL(attn_fwd_fp8_kernel, dim3((unsigned)(nqb * a->B * a->H * p.kv_split)), dim3(NW * 64), LDS, (hipStream_t)stream, p);
+  if (hipGetLastError() != hipSuccess) return V3A_ERR_LAUNCH;
+  if (p.kv_split > 1)
+    return v3a_attn_combine_launch(p.ws_o, p.ws_ml, a->o, a->o_batch_stride, a->ldo, a->B, a->Nq, a->H, D, p.kv_split, p.scale_log2e,
+                                   256.0f * a->v_scale, stream);
+  return V3A_OK;
 }

@@ -112,6 +112,8 @@ class AttnFp8Args(C.Structure):
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int),
         ("scale", C.c_float), ("q_scale", C.c_float), ("k_scale", C.c_float), ("v_scale", C.c_float),
+        ("kv_seg", C.c_int), ("k_seg_stride", C.c_long), ("vt_seg_stride", C.c_long),
+        ("kv_split", C.c_int), ("workspace", C.c_void_p),
     ]
 
 

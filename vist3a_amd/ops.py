@@ -374,14 +374,23 @@ def quantize_fp8_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale
 
 def attention_fp8(q8: torch.Tensor, k8: torch.Tensor, vt8: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Nq: int, Nk: int,
                   q_batch_stride: int, k_batch_stride: int, vt_batch_stride: int, o_batch_stride: int, scale: Optional[float] = None,
-                  q_scale: float = 1.0, k_scale: float = 1.0, v_scale: float = 1.0) -> torch.Tensor:
-    """fp8 (e4m3) flash attention, head dim 128: q8/k8 uint8 [B*N, >=H*128], vt8 uint8 [H*128, >=B*vt_batch_stride], out bf16."""
+                  q_scale: float = 1.0, k_scale: float = 1.0, v_scale: float = 1.0, kv_seg: int = 0, k_seg_stride: int = 0,
+                  vt_seg_stride: int = 0, kv_split: int = 1) -> torch.Tensor:
+    """fp8 (e4m3) flash attention, head dim 128: q8/k8 uint8 [B*N, >=H*128], vt8 uint8 [H*128, >=B*vt_batch_stride], out bf16.
+    kv_seg / k_seg_stride / vt_seg_stride (bytes) and kv_split as in `attention`."""
     for t, n in ((q8, "q8"), (k8, "k8"), (vt8, "vt8")):
         _chk2d(t, n, (torch.uint8,))
     _chk2d(out, "out", (bf16,))
+    ws = None
+    if kv_split > 1:
+        nbytes = L.load().v3a_attention_split_workspace_bytes(B, H, Nq, 128, kv_split)
+        ws = _attn_ws.get(q8.device)
+        if ws is None or ws.numel() < nbytes:
+            ws = _attn_ws[q8.device] = torch.empty(nbytes, device=q8.device, dtype=torch.uint8)
     args = L.AttnFp8Args(_ptr(q8), _ptr(k8), _ptr(vt8), _ptr(out), q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride,
                          q8.stride(0), k8.stride(0), vt8.stride(0), out.stride(0), B, H, Nq, Nk, 128,
-                         float(scale if scale is not None else 128 ** -0.5), float(q_scale), float(k_scale), float(v_scale))
+                         float(scale if scale is not None else 128 ** -0.5), float(q_scale), float(k_scale), float(v_scale),
+                         kv_seg, k_seg_stride, vt_seg_stride, kv_split, _ptr(ws))
     L.check(L.load().v3a_attention_fwd_fp8(C.byref(args), _stream()), "v3a_attention_fwd_fp8")
     return out
 

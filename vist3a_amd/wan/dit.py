@@ -112,6 +112,7 @@ class _Workspace:
             self.q = e(M, d)
             self.pack = e(2 * M * d)
             self.gbuf = e(P, 2 * M * d)
+            self.q8 = self.pack8 = self.gbuf8 = None   # e4m3 forms, allocated on first use of the fp8 attention mode
             self.kfull = e(B * N, d)
             self.vt = torch.zeros(d, B * N + 64, device=device, dtype=bf16)
             self.ogather = e(P, M * self.out.shape[1])
@@ -384,14 +385,34 @@ class WanDiT:
                     ops.gemm(b["wv8"], ws.a8, b["bv"], out=vtl, bias_row=True, a_scale=b["swv"], w_scale=ws.sa)
                 else:
                     ops.gemm(b["wv"], ws.n, b["bv"], out=vtl, bias_row=True)
-                pending = sp.all_gather(ws.gbuf, ws.pack)
+                a8m = self.attn_dtype == "fp8"
+                if a8m:   # e4m3 K | V^T slabs: half the all-gather bytes, attention on the block-scaled MFMA over the gathered slabs
+                    if Nl % 64:
+                        raise NotImplementedError("fp8 attention over sequence-parallel shards needs 64 | tokens per rank")
+                    if ws.pack8 is None:
+                        u8 = lambda *sh: torch.empty(*sh, device=self.device, dtype=torch.uint8)
+                        ws.q8, ws.pack8, ws.gbuf8 = u8(Ml, d), u8(2 * Ml * d), u8(P, 2 * Ml * d)
+                    qs, ksc, vs = self.fp8_scales
+                    ops.quantize_fp8(kl, ksc, out=ws.pack8[:Ml * d].view(Ml, d))
+                    ops.quantize_fp8(vtl, vs, out=ws.pack8[Ml * d:].view(d, Ml))
+                    pending = sp.all_gather(ws.gbuf8, ws.pack8)
+                else:
+                    pending = sp.all_gather(ws.gbuf, ws.pack)
                 if g8:
                     ops.gemm(ws.a8, b["wqk8"][:d], b["bqk"][:d], out=ws.q, a_scale=ws.sa, w_scale=b["swqk"][:d])
                 else:
                     ops.gemm(ws.n, b["wqk"][:d], b["bqk"][:d], out=ws.q)
-                ops.rmsnorm_rope(ws.q, b["nq"], out=ws.q, rope=rope, head_dim=hd, tokens_per_batch=Nl, eps=cfg.eps)
+                if a8m:
+                    ops.rmsnorm_rope(ws.q, b["nq"], out=ws.q8, rope=rope, head_dim=hd, tokens_per_batch=Nl, eps=cfg.eps, fp8_scale=qs)
+                else:
+                    ops.rmsnorm_rope(ws.q, b["nq"], out=ws.q, rope=rope, head_dim=hd, tokens_per_batch=Nl, eps=cfg.eps)
                 pending.wait()
-                if Nl % 64 == 0:
+                if a8m:
+                    ops.attention_fp8(ws.q8, ws.gbuf8[0, :Ml * d].view(Ml, d), ws.gbuf8[0, Ml * d:].view(d, Ml), ws.ao, B=B, H=H, Nq=Nl, Nk=N,
+                                      q_batch_stride=Nl * d, k_batch_stride=Nl * d, vt_batch_stride=Nl, o_batch_stride=Nl * d,
+                                      q_scale=qs, k_scale=ksc, v_scale=vs, kv_seg=Nl, k_seg_stride=2 * Ml * d, vt_seg_stride=2 * Ml * d,
+                                      kv_split=self._sp_split(B, Nl, N))
+                elif Nl % 64 == 0:
                     # the flash kernel walks the gathered slabs in place: rank r's [K | V^T] pack is segment r (keys r*Nl .. (r+1)*Nl)
                     ops.attention(ws.q, ws.gbuf[0, :Ml * d].view(Ml, d), ws.gbuf[0, Ml * d:].view(d, Ml), ws.ao, B=B, H=H, Nq=Nl, Nk=N,
                                   D=hd, q_batch_stride=Nl * d, k_batch_stride=Nl * d, vt_batch_stride=Nl, o_batch_stride=Nl * d,
