@@ -46,18 +46,20 @@ if __name__ == "__main__":
     text = torch.zeros(1, 512, 4096, device="cuda")
     text[0, :64] = torch.randn(64, 4096, device="cuda") * 0.1
     t = torch.tensor([900], device="cuda")
-    lat = torch.randn(1, 16, 4, 64, 64, device="cuda").bfloat16()
+    frames = 6 if "views21" in sys.argv[1:] else 4   # 21 views = 6 latent frames = 6144 tokens (BASELINE config #3)
+    lat = torch.randn(1, 16, frames, 64, 64, device="cuda").bfloat16()
     import os
     if os.environ.get("SP_ONLY"):   # profiling aid: only the sharded forward at P = SP_ONLY (rocprofv3 --kernel-trace --stats -- ...)
         sp = SelfGather(int(os.environ["SP_ONLY"]))
         print(json.dumps(dict(P=sp.world, ms=round(timed(lambda: m(lat, t, text, sp=sp)), 2))))
         sys.exit(0)
     full = timed(lambda: m(lat, t, text))
-    rows = [dict(P=1, B=1, local_tokens=4096, ms=round(full, 2))]
+    ntok = frames * 1024
+    rows = [dict(P=1, B=1, local_tokens=ntok, ms=round(full, 2))]
     for P in (2, 4, 8):
         sp = SelfGather(P)
         ms = timed(lambda: m(lat, t, text, sp=sp))
-        rows.append(dict(P=P, B=1, local_tokens=4096 // P, ms=round(ms, 2), ideal_ms=round(full / P, 2), compute_scaling_eff=round(full / P / ms, 3)))
+        rows.append(dict(P=P, B=1, local_tokens=ntok // P, ms=round(ms, 2), ideal_ms=round(full / P, 2), compute_scaling_eff=round(full / P / ms, 3)))
     # the same forwards replayed from a hipGraph: GPU-side time without the host launch path (~500 launches per forward)
     for P in (1, 2, 4, 8):
         sp = SelfGather(P) if P > 1 else None
@@ -67,6 +69,6 @@ if __name__ == "__main__":
         with torch.cuda.graph(g):
             m(lat, t, text, sp=sp)
         ms = timed(g.replay)
-        rows.append(dict(P=P, B=1, local_tokens=4096 // P, graph_replay_ms=round(ms, 2)))
+        rows.append(dict(P=P, B=1, local_tokens=ntok // P, graph_replay_ms=round(ms, 2)))
     for r in rows:
         print(json.dumps(r))
