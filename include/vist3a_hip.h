@@ -78,6 +78,7 @@ int v3a_gemm_bf16_nt(const v3a_gemm_args* args, void* stream);
 size_t v3a_gemm_split_workspace_bytes(int M, int N, int split_k);
 int v3a_gemm_num_tiles(void);
 int v3a_gemm_pick_tile(int M, int N);   /* the tile index tile=-1 resolves to (profiling / roofline bookkeeping) */
+int v3a_gemm_pick_tile_act(int M, int N, int act);   /* ... for a launch with activation `act` (ties between mirrored tiles depend on it) */
 const char* v3a_gemm_tile_name(int tile);
 
 /* e4m3 (OCP fp8) form of v3a_gemm_bf16_nt for BASELINE config #4 (Wan-14B: "MFMA bf16/fp8 GEMMs for the attention/FFN contractions"):

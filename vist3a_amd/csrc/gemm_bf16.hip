@@ -981,7 +981,7 @@ int g_attr_lds[kNumTiles][2] = {};
 
 // tiles the heuristic may choose from (the rest are explicit / tuning variants); the ping-pong tiles have no conv form
 constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-int pick_tile(int M, int N, bool conv = false, int mult = 1) {
+int pick_tile(int M, int N, bool conv = false, int mult = 1, int act = 0) {
   // Launch time ~ (tiles the busiest CU runs one after another or side by side) x (tile area incl. padding waste) / (measured
   // efficiency of the tile family; fitted to tools/gemm_sweep.py over the production and the sequence-parallel shard shapes).
   // convolutions (fitted to tools/conv_sweep_scene.py): narrow outputs take the narrow tiles - no N padded to 128 / 192 -
@@ -1004,13 +1004,16 @@ int pick_tile(int M, int N, bool conv = false, int mult = 1) {
     double eff = area >= 256 * 192 ? 1.0 : (area >= 128 * 256 ? 0.9 : (area >= 128 * 128 ? 0.8 : (area >= 64 * 128 ? 0.5 : 0.55)));
     if (pp) eff = (i == 7) ? 1.20 : 1.14;  // ping-pong main loop: measured +8..14 % (256x192 / 192x256), more at 256x256
     double cost = (double)rounds * side * area / eff;
+    // with a transcendental activation in the epilogue the 192x256 form (three 32-row groups of 64 columns per wave) measured 1.4 %
+    // faster than 256x192 on FFN1 (-1.0 % on the whole DiT step); without one it is 3 % slower: break the tie by the activation
+    if (i == 8 && act != V3A_ACT_NONE && act != V3A_ACT_RELU) cost *= 0.999;
     if (cost < best - 1e-9) { best = cost; bi = i; }
   }
   return bi;
 }
 
 int launch(const GemmP& p, int ti, bool conv, void* stream, int nz = 1) {
-  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N, conv, nz);
+  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N, conv, nz, p.act);
   const TileEntry& e = kTiles[ti];
   const gemm_fn fn = conv ? e.conv_fn : e.fn;
   if (!fn) return V3A_ERR_ARG;  // this tile shape has no conv instantiation
@@ -1130,6 +1133,7 @@ constexpr int kKnownFlags = V3A_GEMM_BIAS_ROW | V3A_GEMM_SCALE_PER_BATCH | V3A_G
 
 extern "C" int v3a_gemm_num_tiles(void) { return kNumTiles; }
 extern "C" int v3a_gemm_pick_tile(int M, int N) { return (M > 0 && N > 0) ? pick_tile(M, N) : V3A_ERR_SHAPE; }
+extern "C" int v3a_gemm_pick_tile_act(int M, int N, int act) { return (M > 0 && N > 0) ? pick_tile(M, N, false, 1, act) : V3A_ERR_SHAPE; }
 extern "C" const char* v3a_gemm_tile_name(int t) { return (t >= 0 && t < kNumTiles) ? kTiles[t].name : ""; }
 
 extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {

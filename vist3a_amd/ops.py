@@ -172,7 +172,7 @@ def gemm(
             pr.flops += 2.0 * M * N * K
         return out
     pr = _probe
-    if pr is not None and pr.active and not pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile(M, N)) == pr.tile and pr.take():
+    if pr is not None and pr.active and not pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile_act(M, N, act)) == pr.tile and pr.take():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")
