@@ -182,7 +182,7 @@ def main():
     # dominant kernel = the bf16 GEMM tile every N=1536/3072/8960-wide projection resolves to (one kernel symbol)
     f8 = a.dtype == "fp8"   # then the dominant kernel is the e4m3 form of the same tile
     dom_tile = lib.load().v3a_gemm_fp8_pick_tile(2 * N, cfg.dim) if f8 else lib.load().v3a_gemm_pick_tile(2 * N, cfg.dim)
-    # every 7th launch of the symbol is bracketed by events (7 is coprime to the 6 launches of the symbol per DiT block, so every shape is
+    # every 7th launch of the symbol is bracketed by events (7 is coprime to the 5 launches of the symbol per DiT block, so every shape is
     # sampled equally): ~1300 samples per scene, and the event pairs no longer cost the probed scene 3 % of its time
     probe = ops.GemmProbe(dom_tile, fp8=f8, stride=7)
     ops.set_gemm_probe(probe)
