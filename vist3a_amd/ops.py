@@ -63,7 +63,7 @@ def set_gemm_probe(p: Optional[GemmProbe]) -> None:
     _probe = p
 
 
-_gemm_ws = {}   # per-device split-K partial buffer (stream-ordered reuse)
+_gemm_ws = {}   # per (device, thread) split-K partial buffer (see _attn_ws)
 
 
 def gemm(
@@ -151,9 +151,10 @@ def gemm(
         if a_scale is not None:
             raise ValueError("split_k applies to the bf16 GEMM")
         nbytes = L.load().v3a_gemm_split_workspace_bytes(M, N, split_k)
-        ws = _gemm_ws.get(a.device)
+        wk = (a.device, threading.get_ident())
+        ws = _gemm_ws.get(wk)
         if ws is None or ws.numel() < nbytes:
-            ws = _gemm_ws[a.device] = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
+            ws = _gemm_ws[wk] = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
         args.split_k, args.workspace = split_k, ws.data_ptr()
     if a_scale is not None:
         for t, n, nm in ((a_scale, M, "a_scale"), (w_scale, N, "w_scale")):
@@ -305,7 +306,8 @@ def conv(
     return out
 
 
-_attn_ws = {}   # per-device workspace of the key-split attention (stream-ordered reuse)
+_attn_ws = {}   # per (device, thread) workspace of the key-split attention: stream-ordered reuse within a thread; virtual ranks
+                # (seqpar.ThreadWorld: threads sharing one stream) must not share it - their main / merge launches interleave
 
 
 def attention(
@@ -326,9 +328,10 @@ def attention(
     ws = None
     if kv_split > 1:
         nbytes = L.load().v3a_attention_split_workspace_bytes(B, H, Nq, D, kv_split)
-        ws = _attn_ws.get(q.device)
+        wk = (q.device, threading.get_ident())
+        ws = _attn_ws.get(wk)
         if ws is None or ws.numel() < nbytes:
-            ws = _attn_ws[q.device] = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
+            ws = _attn_ws[wk] = torch.empty(nbytes, device=q.device, dtype=torch.uint8)
     if key_bias is not None and (key_bias.dtype != f32 or key_bias.dim() != 2 or key_bias.shape[0] != B or key_bias.stride(1) != 1):
         raise ValueError("key_bias must be fp32 [B, n] with a contiguous last dim")
     if rel_bias is not None and (rel_bias.dtype != f32 or rel_bias.dim() != 2 or rel_bias.shape[0] != H or not rel_bias.is_contiguous()):
@@ -384,9 +387,10 @@ def attention_fp8(q8: torch.Tensor, k8: torch.Tensor, vt8: torch.Tensor, out: to
     ws = None
     if kv_split > 1:
         nbytes = L.load().v3a_attention_split_workspace_bytes(B, H, Nq, 128, kv_split)
-        ws = _attn_ws.get(q8.device)
+        wk = (q8.device, threading.get_ident())
+        ws = _attn_ws.get(wk)
         if ws is None or ws.numel() < nbytes:
-            ws = _attn_ws[q8.device] = torch.empty(nbytes, device=q8.device, dtype=torch.uint8)
+            ws = _attn_ws[wk] = torch.empty(nbytes, device=q8.device, dtype=torch.uint8)
     args = L.AttnFp8Args(_ptr(q8), _ptr(k8), _ptr(vt8), _ptr(out), q_batch_stride, k_batch_stride, vt_batch_stride, o_batch_stride,
                          q8.stride(0), k8.stride(0), vt8.stride(0), out.stride(0), B, H, Nq, Nk, 128,
                          float(scale if scale is not None else 128 ** -0.5), float(q_scale), float(k_scale), float(v_scale),
