@@ -74,8 +74,17 @@ def _lin(x, sd, name, emu, fp8=False):
         return _r(y if b is None else y + b.float(), emu)
     if emu:
         x, w = _r(x, True), _r(w, True)
-    y = F.linear(x, w, None if b is None else b.float())
-    return _r(y, emu)
+    y = _r(F.linear(x, w, None if b is None else b.float()), emu)
+    A = sd.get(name + ".lora_A.weight")
+    if A is not None:
+        # peft LoRA adapter kept UNMERGED, as the reference runs it (inference_t23d.py:74-78: PeftModel.from_pretrained, never
+        # merge_and_unload): peft.tuners.lora.Linear.forward = base(x) + lora_B(lora_A(x)) * (alpha / r); under CUDA bf16 autocast every
+        # nn.Linear output, the scaling product and the sum are separate bf16 roundings.  sd["lora_scaling"] = alpha / r.
+        Bm, sc = sd[name + ".lora_B.weight"], float(sd["lora_scaling"])
+        t = _r(F.linear(x, _r(A.float(), emu)), emu)
+        t = _r(F.linear(t, _r(Bm.float(), emu)), emu)
+        y = _r(y + _r(t * sc, emu), emu)
+    return y
 
 
 def rope_freqs(cfg: WanDiTConfig) -> torch.Tensor:
@@ -120,13 +129,59 @@ def rms_norm(x, w, eps):
     return x.float() * torch.rsqrt(var + eps) * w.float()
 
 
-def attention(q, k, v, heads, emu):
+def attention_flash_emulated(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, key_bias: torch.Tensor | None = None,
+                             key_mask: torch.Tensor | None = None, tile: int = 64, group: int = 32, defer: float = 8.0) -> torch.Tensor:
+    """The rounding points of the MI355X bf16 flash kernel (vist3a_amd/csrc/attention.hip), restated so that the kernel can be checked
+    to fp32 round-off of ITS contract instead of against exact softmax (the reference's own CUDA SDPA is a flash kernel with a bf16 P
+    as well; which tile size and maximum it rounds against is an implementation detail of each).  NOT part of the reference.
+        q [.., Nq, D], k / v [.., Nk, D]: fp32 tensors holding bf16 values -> [.., Nq, D] fp32 (the caller rounds to bf16).
+      * keys are walked in tiles of `tile`; S = q k^T accumulates in fp32 (+ key_bias / scale, masked keys = -1e30);
+      * the exponent reference m of a query row moves (and l, O are rescaled) only when, for some row of its `group`-row wave, the
+        running maximum outgrew m by more than 2^defer - then EVERY row of the wave takes its own running maximum as reference;
+      * p = 2^((s - m) c) in fp32, c = scale * log2(e); l sums the UNROUNDED p; O accumulates bf16(p) . v in fp32;
+      * result O / l."""
+    dev = q.device
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32, device=dev)
+    c = f32(scale) * f32(1.4426950408889634)          # the host computes both constants in fp32
+    lead, Nq, D = q.shape[:-2], q.shape[-2], q.shape[-1]
+    Nk = k.shape[-2]
+    G = (Nq + group - 1) // group
+    pad = G * group - Nq
+    if pad:   # the kernel clamps the rows of a ragged last wave to the last query: duplicates, which cannot change the wave's decision
+        q = torch.cat([q, q[..., -1:, :].expand(*lead, pad, D)], -2)
+    m = torch.full((*lead, G * group), -1e30, dtype=torch.float32, device=dev)
+    l = torch.zeros_like(m)
+    o = torch.zeros((*lead, G * group, D), dtype=torch.float32, device=dev)
+    inv_scale = f32(1.0) / f32(scale)
+    for k0 in range(0, Nk, tile):
+        s = q @ k[..., k0:k0 + tile, :].transpose(-1, -2)
+        if key_bias is not None:
+            s = s + (key_bias[..., k0:k0 + tile] * inv_scale)[..., None, :]
+        if key_mask is not None:
+            s = torch.where(key_mask[k0:k0 + tile], s, torch.full_like(s, -1e30))
+        m_new = torch.maximum(m, s.amax(-1))
+        fire = (((m_new - m) * c) > defer).view(*lead, G, group).any(-1, keepdim=True).expand(*lead, G, group).reshape(*lead, G * group)
+        alpha = torch.where(fire, torch.exp2((m - m_new) * c), torch.ones_like(m))
+        m = torch.where(fire, m_new, m)
+        p = torch.exp2(s * c - (m * c)[..., None])
+        l = l * alpha + p.sum(-1)
+        o = o * alpha[..., None] + p.to(torch.bfloat16).to(torch.float32) @ v[..., k0:k0 + tile, :]
+    return (o / l[..., None])[..., :Nq, :]
+
+
+def attention(q, k, v, heads, emu, flash=False, key_bias=None):
+    """`flash`: emulate the HIP flash kernel's bf16-P rounding (attention_flash_emulated) instead of exact softmax."""
     B, Nq, d = q.shape
     hd = d // heads
     qh = q.view(B, Nq, heads, hd).transpose(1, 2)
     kh = k.view(B, -1, heads, hd).transpose(1, 2)
     vh = v.view(B, -1, heads, hd).transpose(1, 2)
-    o = F.scaled_dot_product_attention(_r(qh, emu), _r(kh, emu), _r(vh, emu))
+    if flash:
+        kb = None if key_bias is None else key_bias[:, None, :]
+        o = attention_flash_emulated(_r(qh, True), _r(kh, True), _r(vh, True), hd ** -0.5, key_bias=kb)
+    else:
+        bias = None if key_bias is None else key_bias[:, None, None, :]
+        o = F.scaled_dot_product_attention(_r(qh, emu), _r(kh, emu), _r(vh, emu), attn_mask=bias)
     return _r(o.transpose(1, 2).reshape(B, Nq, d), emu)
 
 
@@ -141,8 +196,13 @@ def condition_embed(sd, cfg, timestep, text, emu):
     return temb, tproj, ctx
 
 
-def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gemm=False):
-    g8 = fp8_gemm   # the projections of latent tokens (not the per-prompt text K / V) on e4m3 operands
+def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gemm=False, flash=False, ctx_keys=None, fp16_norm=False):
+    """`flash`: attention with the HIP flash kernel's bf16-P rounding points; `ctx_keys` = (Lk, key_bias [B, Lk]) runs the cross-attention
+    over the first Lk context rows with an additive key bias (the product's merged zero-padding key); `fp16_norm`:
+    the reference loads fp16 weights (inference_t23d.py:73) and diffusers' RMSNorm casts its output to the weight dtype, i.e. q / k pass
+    through fp16 before RoPE."""
+    g8 = fp8_gemm
+    h16 = (lambda t: t.to(torch.float16).float()) if fp16_norm else (lambda t: t)   # the projections of latent tokens (not the per-prompt text K / V) on e4m3 operands
     p = f"blocks.{i}."
     d, H, eps = cfg.dim, cfg.num_attention_heads, cfg.eps
     mod = sd[p + "scale_shift_table"].float() + tproj.float()  # [B,6,d]
@@ -152,8 +212,8 @@ def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gem
     q = _lin(n, sd, p + "attn1.to_q", emu, g8)
     k = _lin(n, sd, p + "attn1.to_k", emu, g8)
     v = _lin(n, sd, p + "attn1.to_v", emu, g8)
-    q = rms_norm(q, sd[p + "attn1.norm_q.weight"], eps)
-    k = rms_norm(k, sd[p + "attn1.norm_k.weight"], eps)
+    q = h16(rms_norm(q, sd[p + "attn1.norm_q.weight"], eps))
+    k = h16(rms_norm(k, sd[p + "attn1.norm_k.weight"], eps))
     B, N, _ = q.shape
     q = apply_rope(q.view(B, N, H, -1).transpose(1, 2), freqs).transpose(1, 2).reshape(B, N, d)
     k = apply_rope(k.view(B, N, H, -1).transpose(1, 2), freqs).transpose(1, 2).reshape(B, N, d)
@@ -162,14 +222,17 @@ def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gem
         ao = attention_fp8_emulated(hs(q), hs(k), hs(v), (d // H) ** -0.5).transpose(1, 2).reshape(B, N, d)
         a = _lin(_r(ao, emu), sd, p + "attn1.to_out.0", emu, g8)
     else:
-        a = _lin(attention(q, k, v, H, emu), sd, p + "attn1.to_out.0", emu, g8)
+        a = _lin(attention(q, k, v, H, emu, flash), sd, p + "attn1.to_out.0", emu, g8)
     x = _r(x.float() + a * gate_msa, emu)
     # 2. cross attention (norm2 has affine, no modulation; no mask over zero-padded text rows)
     n = _r(F.layer_norm(x.float(), (d,), sd[p + "norm2.weight"].float(), sd[p + "norm2.bias"].float(), eps), emu)
-    q = rms_norm(_lin(n, sd, p + "attn2.to_q", emu, g8), sd[p + "attn2.norm_q.weight"], eps)
-    k = rms_norm(_lin(ctx, sd, p + "attn2.to_k", emu), sd[p + "attn2.norm_k.weight"], eps)
+    q = h16(rms_norm(_lin(n, sd, p + "attn2.to_q", emu, g8), sd[p + "attn2.norm_q.weight"], eps))
+    k = h16(rms_norm(_lin(ctx, sd, p + "attn2.to_k", emu), sd[p + "attn2.norm_k.weight"], eps))
     v = _lin(ctx, sd, p + "attn2.to_v", emu)
-    a = _lin(attention(q, k, v, H, emu), sd, p + "attn2.to_out.0", emu, g8)
+    kb = None
+    if ctx_keys is not None:
+        k, v, kb = k[:, :ctx_keys[0]], v[:, :ctx_keys[0]], ctx_keys[1]
+    a = _lin(attention(q, k, v, H, emu, flash, kb), sd, p + "attn2.to_out.0", emu, g8)
     x = _r(x + a, emu)
     # 3. feed forward
     n = _r(F.layer_norm(x.float(), (d,), eps=eps) * (1 + c_scale) + c_shift, emu)
@@ -195,11 +258,29 @@ def unpatchify(cfg, tokens, Fr, Hh, Ww):
     return x.flatten(6, 7).flatten(4, 5).flatten(2, 3)
 
 
+def merged_padding_keys(text: torch.Tensor):
+    """The product's cross-attention key set for a zero-padded prompt (vist3a_amd/wan/dit.py::_context, DESIGN.md section 4): the
+    trailing all-zero rows [n_real, L) have identical K / V, so rows [Lk-1, L) are represented by ONE key with bias log(count), Lk =
+    n_real + 1 rounded up to 8.  Returns (Lk, key_bias [B, Lk]) or None when nothing is merged.  Exact in real arithmetic."""
+    B, Lt, _ = text.shape
+    nz = (text != 0).any(-1)
+    n_real = max((int(nz[b].nonzero().max()) + 1 if nz[b].any() else 0) for b in range(B))
+    Lk = (n_real + 1 + 7) // 8 * 8
+    if Lk + 1 >= Lt:
+        return None
+    kb = torch.zeros(B, Lk)
+    kb[:, Lk - 1] = math.log(Lt - (Lk - 1))
+    return Lk, kb
+
+
 def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.Tensor, timestep: torch.Tensor,
                 text: torch.Tensor, emulate_bf16: bool = False, num_layers: int | None = None, fp8_attn: bool = False,
-                fp8_gemm: bool = False) -> torch.Tensor:
-    """transformer(hidden_states[B,16,T,H,W], timestep[B], encoder_hidden_states[B,L,4096]) -> [B,16,T,H,W]."""
+                fp8_gemm: bool = False, flash: bool = False, merge_padding: bool = False, fp16_norm: bool = False) -> torch.Tensor:
+    """transformer(hidden_states[B,16,T,H,W], timestep[B], encoder_hidden_states[B,L,4096]) -> [B,16,T,H,W].
+    `flash` / `merge_padding` switch on the two places where the HIP path's CONTRACT differs from exact softmax over all 512 context
+    rows (bf16 P per 64-key tile; one merged zero-padding key) so that a full-depth comparison measures the kernels, not those."""
     emu = emulate_bf16
+    ctx_keys = merged_padding_keys(text) if merge_padding else None
     B, C, Fr, Hh, Ww = latents.shape
     pt, ph, pw = cfg.patch_size
     freqs = rope_for_grid(cfg, Fr // pt, Hh // ph, Ww // pw)
@@ -209,7 +290,7 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.T
     temb, tproj, ctx = condition_embed(sd, cfg, timestep, text, emu)
     L = cfg.num_layers if num_layers is None else num_layers
     for i in range(L):
-        x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn, fp8_gemm)
+        x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn, fp8_gemm, flash, ctx_keys, fp16_norm)
     shift, scale = (sd["scale_shift_table"].float() + temb.float().unsqueeze(1)).chunk(2, dim=1)
     x = _r(F.layer_norm(x.float(), (cfg.dim,), eps=cfg.eps) * (1 + scale) + shift, emu)
     x = _lin(x, sd, "proj_out", emu)
@@ -249,6 +330,22 @@ def make_weights(cfg: WanDiTConfig, seed: int = 0, dtype=torch.float32) -> Dict[
     sd["scale_shift_table"] = (torch.randn(1, 2, d, generator=g) / math.sqrt(d)).to(dtype)
     lin("proj_out", cfg.out_channels * pt * ph * pw, d)
     return sd
+
+
+def with_lora_adapter(sd, cfg, r=8, alpha=16, seed=9, std=0.05):
+    """Adapter tensors on the reference's eight target modules of every block (train_vdm.py:369-384: r = 8, alpha = 16), peft key names."""
+    g = torch.Generator().manual_seed(seed)
+    out, peft = dict(sd), {}
+    for i in range(cfg.num_layers):
+        for a in ("attn1", "attn2"):
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                name = f"blocks.{i}.{a}.{n}"
+                A = torch.randn(r, cfg.dim, generator=g) * std
+                B = torch.randn(cfg.dim, r, generator=g) * std      # (peft initialises B = 0; a trained adapter has both non-zero)
+                out[name + ".lora_A.weight"], out[name + ".lora_B.weight"] = A, B
+                peft[f"base_model.model.{name}.lora_A.weight"], peft[f"base_model.model.{name}.lora_B.weight"] = A, B
+    out["lora_scaling"] = torch.tensor(alpha / r)
+    return out, peft
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -200,6 +200,61 @@ def recon_tiny():
     })
 
 
+RECON_MH = dict(C=128, heads=2, n_dino=22, depth=24, cam_heads=4, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+
+
+def recon_mh():
+    """recon_tiny at width 128 = TWO heads of 64 (the production head size): pins the per-head layout of qkv / q_norm / k_norm / RoPE2D /
+    attention (vggt/layers/attention.py:49-80, rope.py:154-188) and a 4-head camera trunk, which a one-head model cannot see.
+    3 views @28x42 (non-square, so hp != wp in the RoPE position grid)."""
+    from oracle import recon as R
+    cfg = R.ReconCfg(**RECON_MH)
+    sd = R.make_recon_weights(cfg, seed=43)
+    model = build_reference_stitched(cfg, sd)
+    g = torch.Generator().manual_seed(44)
+    S, H, W = 3, 28, 42
+    lat = torch.randn(1, cfg.C, S, H // 14, W // 14, generator=g)
+    img = torch.rand(1, 3, S, H, W, generator=g) * 2 - 1
+    import contextlib, io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        ref = model(lat, img, False)
+        mine = R.recon_forward(sd, cfg, lat, img)
+    gs = ref.gaussians
+
+    def chk(name, a, b, tol=2e-4):
+        e = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-9)
+        print(f"  {name:22s} rel-max err {e:.2e}  shape {tuple(b.shape)}")
+        assert e < tol, name
+
+    print("recon_mh: oracle vs reference")
+    chk("pose_enc", mine["pred_pose_enc_list"][-1], ref.pred_pose_enc_list[-1])
+    chk("depth", mine["depth"], ref.depth_dict["depth"])
+    chk("means", mine["gaussians"]["means"], gs.means)
+    chk("scales", mine["gaussians"]["scales"], gs.scales)
+    chk("opacities", mine["gaussians"]["opacities"], gs.opacities)
+    chk("c2w", mine["pred_context_pose"]["extrinsic"], ref.pred_context_pose["extrinsic"])
+    # a one-head restatement of the same weights must NOT reproduce it (the fixture really sees the head split)
+    import copy
+    c1 = copy.copy(cfg)
+    c1.heads, c1.cam_heads = 1, 1
+    sd1 = dict(sd)
+    for k in list(sd1):
+        if "attn.q_norm" in k or "attn.k_norm" in k:
+            sd1[k] = sd1[k].repeat(2)
+    with torch.no_grad():
+        wrong = R.recon_forward(sd1, c1, lat, img)
+    d = (wrong["depth"] - ref.depth_dict["depth"]).abs().max().item() / ref.depth_dict["depth"].abs().max().item()
+    print(f"  one-head restatement differs in depth by {d:.2e} (must be large)")
+    assert d > 1e-2
+    _save("recon_mh", {
+        "latent": lat, "image": img,
+        "pose_enc_list": torch.stack(ref.pred_pose_enc_list), "depth": ref.depth_dict["depth"],
+        "means": gs.means, "scales": gs.scales, "rotations": gs.rotations, "opacities": gs.opacities,
+        "c2w": ref.pred_context_pose["extrinsic"], "intrinsic": ref.pred_context_pose["intrinsic"],
+        "scene_scale": ref.infos["scene_scale"].reshape(1),
+    })
+
+
 def voxel_collide():
     """EncoderAnySplat.voxelizaton_with_fusion on points engineered to collide (several points per voxel, negative
     coordinates, exact .5 rounding ties): integer keys / inverse / counts are the bit-exact contract."""
@@ -250,7 +305,7 @@ def recon_tiny_conf():
                               "means": gs.means, "opacities": gs.opacities, "scales": gs.scales})
 
 
-GENERATORS = {f.__name__: f for f in [vae_decode_tiny, vae_encode_tiny, stitch_tiny, recon_tiny, recon_tiny_conf, voxel_collide]}
+GENERATORS = {f.__name__: f for f in [vae_decode_tiny, vae_encode_tiny, stitch_tiny, recon_tiny, recon_mh, recon_tiny_conf, voxel_collide]}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)

@@ -189,10 +189,17 @@ def test_merge_lora_matches_reference_eval_merge_golden():
     y = torch.nn.functional.linear(torch.nn.functional.linear(io["x"], sd["blocks.0.qkv.weight"], sd["blocks.0.qkv.bias"])[..., :12], sd["blocks.1.proj.weight"])
     z = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(io["img"], sd["head.0.weight"], sd["head.0.bias"], padding=1)), sd["head.2.weight"], sd["head.2.bias"])
     assert torch.allclose(y, io["y"], atol=1e-5) and torch.allclose(z, io["z"], atol=1e-5)
-    # unknown keys must not be dropped silently
+    # a key of a layer this engine HAS but cannot take (wrong shape) must not be dropped silently ...
     import pytest
     with pytest.raises(KeyError):
-        merge_lora({k: v.clone() for k, v in base.items()}, {**lora, "blocks.7.qkv.bias": torch.zeros(36)}, 16.0, 4)
+        merge_lora({k: v.clone() for k, v in base.items()}, {**lora, "blocks.0.qkv.bias": torch.zeros(5)}, 16.0, 4)
+    # ... while adapters of layers that are not part of the engine at all (the reference wraps every Linear / Conv2d and loads with
+    # strict=False: dropped DINO blocks, unused heads) are skipped with ONE warning and leave the result unchanged
+    sd2 = {k: v.clone() for k, v in base.items()}
+    with pytest.warns(UserWarning, match="skipped 3 adapter tensors"):
+        n2 = merge_lora(sd2, {**lora, "blocks.7.qkv.bias": torch.zeros(36), "blocks.7.qkv.lora_A": torch.zeros(4, 12),
+                              "blocks.7.qkv.lora_B": torch.zeros(36, 4)}, float(meta["alpha"]), int(meta["r"]))
+    assert n2 == 6 and all(torch.equal(sd2[k], sd[k]) for k in sd)
 
 
 def test_parse_lora_mode_matches_reference_parser_golden():

@@ -180,6 +180,11 @@ def test_gemm_rejects_unknown_flag_bits(hip_lib):
 
 
 # ---------------------------------------------------------------- attention ----
+# vs exact fp32 softmax attention: bounded by the bf16 P operand (2.2-2.4e-3 measured on every shape; every flash kernel incl. the
+# reference's CUDA SDPA has this term).  vs the kernel's own rounding contract (bf16 P emulated): fp32 round-off + the bf16 flips of the
+# output it causes - THIS is the gate that shows whether the kernel computes what it says (north_star: 1e-3).
+TOL_ATTN_EXACT = 4.5e-3
+TOL_ATTN_CONTRACT = 1e-3
 def _attn_inputs(B, H, Nq, Nk, D, g, scale=1.0):
     q = (torch.randn(B, Nq, H * D, device=dev, generator=g) * scale).to(bf16)
     k = (torch.randn(B, Nk, H * D, device=dev, generator=g) * scale).to(bf16)
@@ -206,6 +211,16 @@ def _attn_ref(q, k, v, B, H, D, bias=None, mask=None):
     return torch.stack(outs, 2).reshape(B, -1, H * D)
 
 
+def _attn_emu(q, k, v, B, H, D, bias=None, mask=None):
+    """The kernel's CONTRACT (oracle.wan_dit.attention_flash_emulated: bf16 P per 64-key tile against the deferred per-wave exponent
+    reference, fp32 everywhere else), evaluated with torch on the GPU, output rounded to bf16 like the kernel's."""
+    from oracle.wan_dit import attention_flash_emulated
+    hs = lambda t: t.float().view(B, -1, H, D).transpose(1, 2)
+    kb = None if bias is None else bias[:, None, :]
+    o = attention_flash_emulated(hs(q), hs(k), hs(v), D ** -0.5, key_bias=kb, key_mask=mask)
+    return o.transpose(1, 2).reshape(B, -1, H * D).to(bf16)
+
+
 def _run_attn(q, k, vt, nkp, B, H, Nq, Nk, D, **kw):
     from vist3a_amd import ops
     out = torch.empty(B * Nq, H * D, device=dev, dtype=bf16)
@@ -221,10 +236,10 @@ def test_attention_hd128_dit_self_attention_shape(hip_lib, parity):
     g = torch.Generator(device=dev).manual_seed(11)
     q, k, v, vt, nkp = _attn_inputs(B, H, N, N, D, g)
     out = _run_attn(q, k, vt, nkp, B, H, N, N, D)
-    r = relerr(out, _attn_ref(q, k, v, B, H, D))
-    parity("attention_hd128_self", B=B, H=H, Nq=N, Nk=N, rel_vs_fp32=r)
-    print(f"hd128 4096x4096 rel {r:.2e}")
-    assert r < 5e-3, r
+    r, re = relerr(out, _attn_ref(q, k, v, B, H, D)), relerr(out, _attn_emu(q, k, v, B, H, D))
+    parity("attention_hd128_self", B=B, H=H, Nq=N, Nk=N, rel_vs_fp32=r, rel_vs_contract=re)
+    print(f"hd128 4096x4096 rel vs exact softmax {r:.2e}, vs the kernel's rounding contract {re:.2e}")
+    assert r < TOL_ATTN_EXACT and re < TOL_ATTN_CONTRACT, (r, re)
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,S", [(1, 12, 1024, 4096, 8), (2, 12, 512, 4096, 5), (1, 40, 1000, 4096 + 37, 3), (2, 3, 130, 200, 4)])
@@ -253,9 +268,9 @@ def test_attention_hd128_cross_attention_merged_padding_keys(hip_lib, parity):
     kb = torch.zeros(B, nkp, device=dev)
     kb[:, Nk - 1] = math.log(512 - (Nk - 1))
     out = _run_attn(q, k, vt, nkp, B, H, Nq, Nk, D, key_bias=kb, key_bias_first=Nk - 1)
-    r = relerr(out, _attn_ref(q, k, v, B, H, D, bias=kb[:, :Nk]))
-    parity("attention_hd128_cross_keybias", B=B, H=H, Nq=Nq, Nk=Nk, rel_vs_fp32=r)
-    assert r < 5e-3, r
+    r, re = relerr(out, _attn_ref(q, k, v, B, H, D, bias=kb[:, :Nk])), relerr(out, _attn_emu(q, k, v, B, H, D, bias=kb[:, :Nk]))
+    parity("attention_hd128_cross_keybias", B=B, H=H, Nq=Nq, Nk=Nk, rel_vs_fp32=r, rel_vs_contract=re)
+    assert r < TOL_ATTN_EXACT and re < TOL_ATTN_CONTRACT, (r, re)
 
 
 def test_attention_hd64_global_attention_production_mask(hip_lib, parity):
@@ -268,10 +283,10 @@ def test_attention_hd64_global_attention_production_mask(hip_lib, parity):
     out = _run_attn(q, k, vt, nkp, 1, H, N, N, D, kv_period=Pp, kv_valid=P)
     mask = (torch.arange(N, device=dev) % Pp) < P
     ref = _attn_ref(q, k, v, 1, H, D, mask=mask)
-    r = relerr(out[:, mask], ref[:, mask])
-    parity("attention_hd64_global_masked", S=S, Pp=Pp, valid=P, H=H, rel_vs_fp32=r)
-    print(f"hd64 global masked rel {r:.2e}")
-    assert r < 5e-3, r
+    r, re = relerr(out[:, mask], ref[:, mask]), relerr(out[:, mask], _attn_emu(q, k, v, 1, H, D, mask=mask)[:, mask])
+    parity("attention_hd64_global_masked", S=S, Pp=Pp, valid=P, H=H, rel_vs_fp32=r, rel_vs_contract=re)
+    print(f"hd64 global masked rel vs exact softmax {r:.2e}, vs contract {re:.2e}")
+    assert r < TOL_ATTN_EXACT and re < TOL_ATTN_CONTRACT, (r, re)
 
 
 def test_attention_hd64_frame_attention_production_shape(hip_lib, parity):
@@ -279,9 +294,9 @@ def test_attention_hd64_frame_attention_production_shape(hip_lib, parity):
     g = torch.Generator(device=dev).manual_seed(14)
     q, k, v, vt, nkp = _attn_inputs(S, H, P, P, D, g)
     out = _run_attn(q, k, vt, nkp, S, H, P, P, D)
-    r = relerr(out, _attn_ref(q, k, v, S, H, D))
-    parity("attention_hd64_frame", B=S, H=H, N=P, rel_vs_fp32=r)
-    assert r < 5e-3, r
+    r, re = relerr(out, _attn_ref(q, k, v, S, H, D)), relerr(out, _attn_emu(q, k, v, S, H, D))
+    parity("attention_hd64_frame", B=S, H=H, N=P, rel_vs_fp32=r, rel_vs_contract=re)
+    assert r < TOL_ATTN_EXACT and re < TOL_ATTN_CONTRACT, (r, re)
 
 
 def test_attention_spiked_scores_force_running_max_jumps(hip_lib, parity):
@@ -292,9 +307,9 @@ def test_attention_spiked_scores_force_running_max_jumps(hip_lib, parity):
     k[0, 700, :D] = (q[0, 5, :D].float() * 4).to(bf16)
     k[0, 70, D:] = (q[0, 77, D:].float() * 3).to(bf16)
     out = _run_attn(q, k, vt, nkp, B, H, Nq, Nk, D)
-    r = relerr(out, _attn_ref(q, k, v, B, H, D))
-    parity("attention_spiked", rel_vs_fp32=r)
-    assert r < 5e-3, r
+    r, re = relerr(out, _attn_ref(q, k, v, B, H, D)), relerr(out, _attn_emu(q, k, v, B, H, D))
+    parity("attention_spiked", rel_vs_fp32=r, rel_vs_contract=re)
+    assert r < TOL_ATTN_EXACT and re < TOL_ATTN_CONTRACT, (r, re)
 
 
 # ---------------------------------------------------------------- convolution ----

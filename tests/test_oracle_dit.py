@@ -73,3 +73,66 @@ def test_forward_shapes_and_bf16_emulation_close():
     # batch independence (CFG batching must equal two B=1 calls)
     a0 = O.dit_forward(sd, cfg, lat[:1], t[:1], text[:1])
     assert torch.allclose(a[:1], a0, atol=1e-5)
+
+
+def test_flash_emulation_is_softmax_up_to_bf16_p_and_handles_spikes_masks_and_bias():
+    """attention_flash_emulated restates the HIP flash kernel's rounding points; in exact arithmetic it IS softmax attention."""
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(2, 3, 70, 64, generator=g).bfloat16().float()
+    k = torch.randn(2, 3, 200, 64, generator=g).bfloat16().float()
+    v = torch.randn(2, 3, 200, 64, generator=g).bfloat16().float()
+    k[0, 1, 150] = q[0, 1, 5] * 6     # the running maximum of one row jumps by far more than 2^8 at the third tile
+    ref = torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    for defer in (0.0, 8.0):
+        assert rel(O.attention_flash_emulated(q, k, v, 0.125, defer=defer), ref) < 3e-3
+    # per-key bias and key mask
+    kb = torch.zeros(2, 1, 200)
+    kb[..., 199] = math.log(313.0)
+    ref_b = torch.softmax(q @ k.transpose(-1, -2) * 0.125 + kb[:, :, None, :], -1) @ v
+    assert rel(O.attention_flash_emulated(q, k, v, 0.125, key_bias=kb), ref_b) < 3e-3
+    mask = (torch.arange(200) % 40) < 37
+    ref_m = torch.softmax((q @ k.transpose(-1, -2) * 0.125).masked_fill(~mask, float("-inf")), -1) @ v
+    assert rel(O.attention_flash_emulated(q, k, v, 0.125, key_mask=mask), ref_m) < 3e-3
+    # a ragged last wave (70 = 2 x 32 + 6 rows) gives the rows it has the same result as when they are computed alone in their wave
+    alone = O.attention_flash_emulated(q[..., 64:, :], k, v, 0.125, defer=0.0)
+    assert torch.allclose(O.attention_flash_emulated(q, k, v, 0.125, defer=0.0)[..., 64:, :], alone, atol=1e-6)
+
+
+def test_merged_padding_key_is_exact_and_option_switches_compose():
+    cfg, sd = TINY, O.make_weights(TINY, seed=3)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(2, 16, 1, 8, 8, generator=g)
+    text = torch.randn(2, 96, cfg.text_dim, generator=g) * 0.5
+    text[0, 20:] = 0
+    text[1, 33:] = 0
+    t = torch.tensor([500, 500])
+    Lk, kb = O.merged_padding_keys(text)
+    assert Lk == 40 and kb.shape == (2, 40) and abs(kb[0, 39].item() - math.log(96 - 39)) < 1e-6 and kb[:, :39].abs().max() == 0
+    full = O.dit_forward(sd, cfg, lat, t, text)
+    merged = O.dit_forward(sd, cfg, lat, t, text, merge_padding=True)
+    assert torch.allclose(full, merged, atol=2e-5, rtol=1e-5)
+    assert O.merged_padding_keys(torch.randn(1, 16, 8)) is None
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    emu = O.dit_forward(sd, cfg, lat, t, text, emulate_bf16=True)
+    assert rel(O.dit_forward(sd, cfg, lat, t, text, emulate_bf16=True, flash=True, merge_padding=True), emu) < 1e-2
+    assert rel(O.dit_forward(sd, cfg, lat, t, text, emulate_bf16=True, fp16_norm=True), emu) < 5e-3
+
+
+def test_unmerged_lora_equals_merged_weights_in_fp32():
+    """Wx + (alpha/r) B(Ax) == (W + (alpha/r) BA) x: the oracle's unmerged adapter path (what the reference executes) against the
+    merge the product performs at load (vist3a_amd.wan.dit.merge_lora_into_state_dict, pure tensor algebra: importable without a GPU)."""
+    from vist3a_amd.wan.dit import merge_lora_into_state_dict
+    cfg, base = TINY, O.make_weights(TINY, seed=3)
+    sd_l, peft = O.with_lora_adapter(base, cfg)
+    merged = {k: v.clone() for k, v in base.items()}
+    assert merge_lora_into_state_dict(merged, peft, alpha=16, r=8) == 8 * cfg.num_layers
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 16, 1, 8, 8, generator=g)
+    text = torch.randn(1, 24, cfg.text_dim, generator=g) * 0.5
+    t = torch.tensor([300])
+    a = O.dit_forward(sd_l, cfg, lat, t, text)
+    b = O.dit_forward(merged, cfg, lat, t, text)
+    plain = O.dit_forward(base, cfg, lat, t, text)
+    rel = lambda x, y: ((x - y).norm() / y.norm()).item()
+    assert rel(a, b) < 2e-6 and rel(a, plain) > 1e-2     # identical map; and the adapter really changes the output

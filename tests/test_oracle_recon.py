@@ -41,6 +41,28 @@ def test_recon_forward_golden():
     assert torch.allclose(o["scene_scale"].reshape(1), g["scene_scale"], rtol=1e-5)
 
 
+RECON_MH = dict(C=128, heads=2, n_dino=22, depth=24, cam_heads=4, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+
+
+def test_recon_multi_head_golden():
+    """Two heads of 64 + a four-head camera trunk, 3 views @28x42 (tests/golden/make_golden.py::recon_mh, the reference's own
+    AnySplatStitched.forward): pins the per-head split of qkv / q_norm / k_norm / RoPE2D that the one-head fixture cannot see."""
+    g = load_file(str(G / "recon_mh.safetensors"))
+    cfg = R.ReconCfg(**RECON_MH)
+    sd = R.make_recon_weights(cfg, seed=43)
+    with torch.no_grad():
+        o = R.recon_forward(sd, cfg, g["latent"], g["image"])
+    gs = o["gaussians"]
+    assert torch.allclose(torch.stack(o["pred_pose_enc_list"]), g["pose_enc_list"], atol=2e-5)
+    assert torch.allclose(o["depth"], g["depth"], rtol=2e-4, atol=1e-5)
+    assert gs["means"].shape == g["means"].shape and torch.allclose(gs["means"], g["means"], atol=2e-5)
+    assert torch.allclose(gs["scales"], g["scales"], rtol=1e-4, atol=1e-8)
+    assert torch.allclose(gs["rotations"], g["rotations"], atol=2e-5)
+    assert torch.allclose(gs["opacities"], g["opacities"], atol=2e-5)
+    assert torch.allclose(o["pred_context_pose"]["extrinsic"], g["c2w"], atol=2e-5)
+    assert torch.allclose(o["pred_context_pose"]["intrinsic"], g["intrinsic"], atol=2e-5)
+
+
 def test_voxel_golden_bit_exact_integers():
     g = load_file(str(G / "voxel_collide.safetensors"))
     vp, vf, keys, inv, cnt = R.voxelize_with_fusion(g["feat"], g["pts"], 0.002, g["conf"])

@@ -92,6 +92,34 @@ def test_engine_matches_reference_golden(tiny):
         assert abs(a.mean().item() - b.mean().item()) <= 2e-2 * abs(b.mean().item()) + 1e-6, k
 
 
+RECON_MH = dict(C=128, heads=2, n_dino=22, depth=24, cam_heads=4, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+
+
+def test_engine_multi_head_matches_reference_golden(hip_lib, parity):
+    """TWO heads of 64 (+ a four-head fp32 camera trunk), 3 views @28x42: the reference's own AnySplatStitched.forward output
+    (tests/golden/make_golden.py::recon_mh).  A wrong per-head layout of q / k / V^T, of the head-wise q_norm / k_norm or of the RoPE2D
+    position lookup (hp != wp here) moves depth by > 1e-1 (the generator asserts that for a one-head restatement)."""
+    from vist3a_amd.recon.engine import ReconCfg, ReconEngine
+    g = load_file(str(G / "recon_mh.safetensors"))
+    ocfg = R.ReconCfg(**RECON_MH)
+    sd = R.make_recon_weights(ocfg, seed=43)
+    eng = ReconEngine(ReconCfg(**RECON_MH), sd)
+    S, H, W = 3, 28, 42
+    out = eng.forward(g["latent"].cuda(), g["image"].cuda())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        otaps = R.backbone(sd, g["latent"], 1, S, (H, W), ocfg.heads, ocfg.n_dino, ocfg.depth)
+    _, geo = eng.token_workspace(S, H, W)
+    tap_err = [_rel(geo["taps"][i].view(S, geo["Pp"], -1)[:, :geo["P"]], t[0]) for i, t in enumerate(otaps)]
+    poses = torch.stack([p.cpu() for p in out["pred_pose_enc_list"]])[:, None]
+    r_pose, r_depth = _rel(poses, g["pose_enc_list"]), _rel(out["depth"], g["depth"][0, ..., 0])
+    U, Ug = out["gaussians"]["means"].shape[0], g["means"].shape[1]
+    parity("recon_multi_head_golden", taps=tap_err, pose=r_pose, depth=r_depth, voxels=U, voxels_reference=Ug)
+    print("multi-head golden: taps", [f"{e:.1e}" for e in tap_err], f"pose {r_pose:.2e} depth {r_depth:.2e} voxels {U} vs {Ug}")
+    assert max(tap_err) < 3e-2 and r_pose < 3e-2 and r_depth < 2e-2
+    assert abs(U - Ug) <= 0.05 * Ug
+
+
 def test_heads_on_oracle_tokens(tiny):
     """Isolate the heads from backbone rounding: inject the ORACLE's tapped tokens, then the fp32 camera head must agree to
     1e-4 and the bf16 DPT heads to 1e-2."""

@@ -198,6 +198,7 @@ SYMBOLS = {
 }
 
 _lib = None
+EXPECTED_ABI = 14   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
 
 
 class HipLibraryError(RuntimeError):
@@ -227,6 +228,10 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
             raise HipLibraryError(f"{p} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    got = lib.v3a_abi_version()
+    if got != EXPECTED_ABI:   # a stale in-tree .so would read the structs above past their old end
+        raise HipLibraryError(f"{p} has ABI version {got}, this package binds version {EXPECTED_ABI}: rebuild it with "
+                              "`python -m vist3a_amd.build`")
     _lib = lib
     return lib
 

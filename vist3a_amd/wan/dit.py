@@ -474,7 +474,9 @@ class GraphedWanDiT:
             return self.dit.forward(hidden_states, timestep, encoder_hidden_states, return_dict, num_layers, sp)
         text = encoder_hidden_states
         lk = self.dit._context(text)[5]  # eager: refreshes the persistent K / V^T buffers when the prompt changed
-        key = (tuple(hidden_states.shape), tuple(text.shape), lk, threading.get_ident())
+        d = self.dit   # the precision modes are baked into a capture: a flipped mode must not replay the old-precision graph
+        key = (tuple(hidden_states.shape), tuple(text.shape), lk, threading.get_ident(), d.attn_dtype, d.gemm_dtype, tuple(d.fp8_scales),
+               d.merge_padding_keys)
         ent = self._graphs.get(key)
         if ent is None:
             sx = torch.empty(hidden_states.shape, device=self.device, dtype=bf16)
