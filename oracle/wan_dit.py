@@ -275,10 +275,12 @@ def merged_padding_keys(text: torch.Tensor):
 
 def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.Tensor, timestep: torch.Tensor,
                 text: torch.Tensor, emulate_bf16: bool = False, num_layers: int | None = None, fp8_attn: bool = False,
-                fp8_gemm: bool = False, flash: bool = False, merge_padding: bool = False, fp16_norm: bool = False) -> torch.Tensor:
+                fp8_gemm: bool = False, flash: bool = False, merge_padding: bool = False, fp16_norm: bool = False,
+                depth_outputs: dict | None = None) -> torch.Tensor:
     """transformer(hidden_states[B,16,T,H,W], timestep[B], encoder_hidden_states[B,L,4096]) -> [B,16,T,H,W].
     `flash` / `merge_padding` switch on the two places where the HIP path's CONTRACT differs from exact softmax over all 512 context
-    rows (bf16 P per 64-key tile; one merged zero-padding key) so that a full-depth comparison measures the kernels, not those."""
+    rows (bf16 P per 64-key tile; one merged zero-padding key) so that a full-depth comparison measures the kernels, not those.
+    `depth_outputs` = {L: None, ...}: filled with the model output truncated after L blocks (== num_layers=L), for error-vs-depth curves."""
     emu = emulate_bf16
     ctx_keys = merged_padding_keys(text) if merge_padding else None
     B, C, Fr, Hh, Ww = latents.shape
@@ -289,12 +291,17 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.T
     x = _r(F.linear(_r(tok, emu), _r(w, emu), sd["patch_embedding.bias"].float()), emu)
     temb, tproj, ctx = condition_embed(sd, cfg, timestep, text, emu)
     L = cfg.num_layers if num_layers is None else num_layers
+    shift, scale = (sd["scale_shift_table"].float() + temb.float().unsqueeze(1)).chunk(2, dim=1)
+
+    def head(h):   # norm_out + modulation + proj_out + unpatchify
+        h = _r(F.layer_norm(h.float(), (cfg.dim,), eps=cfg.eps) * (1 + scale) + shift, emu)
+        return unpatchify(cfg, _lin(h, sd, "proj_out", emu), Fr, Hh, Ww)
+
     for i in range(L):
         x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn, fp8_gemm, flash, ctx_keys, fp16_norm)
-    shift, scale = (sd["scale_shift_table"].float() + temb.float().unsqueeze(1)).chunk(2, dim=1)
-    x = _r(F.layer_norm(x.float(), (cfg.dim,), eps=cfg.eps) * (1 + scale) + shift, emu)
-    x = _lin(x, sd, "proj_out", emu)
-    return unpatchify(cfg, x, Fr, Hh, Ww)
+        if depth_outputs is not None and (i + 1) in depth_outputs:
+            depth_outputs[i + 1] = head(x)      # what dit_forward(num_layers=i+1) returns, from the one pass
+    return head(x)
 
 
 def make_weights(cfg: WanDiTConfig, seed: int = 0, dtype=torch.float32) -> Dict[str, torch.Tensor]:

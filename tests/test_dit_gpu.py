@@ -14,8 +14,8 @@ from oracle import wan_dit as O
 pytestmark = pytest.mark.gpu
 
 # full-depth production forward (30 blocks, 4096 tokens), asserted at <= 2x what MI355X measured (profiles/r3/parity.json)
-TOL_FULL_DEPTH_EXACT = 2e-2
-TOL_FULL_DEPTH_CONTRACT = 2e-2
+TOL_FULL_DEPTH = 1.8e-2     # measured 9.1e-3 (both oracles)
+TOL_ONE_BLOCK = 3e-3        # measured ~1.5e-3 after one block
 
 TINY = dict(num_attention_heads=2, attention_head_dim=128, ffn_dim=512, num_layers=2, text_dim=128, freq_dim=64)
 
@@ -316,20 +316,31 @@ def test_full_depth_production_size_forward_matches_oracle(hip_lib, parity):
     text = (torch.randn(1, 512, cfg.text_dim, generator=g) * 0.5).to(torch.bfloat16).float()
     text[:, 77:] = 0
     t = torch.tensor([700])
-    out = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
+    depths = (1, 2, 4, 8, 16, 30)
+    outs = {L: model(lat.cuda(), t.cuda(), text.cuda(), num_layers=L)[0].float().cpu() for L in depths}
+    out = outs[30]
     torch.cuda.synchronize()
     with torch.no_grad():
         ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
         # the same forward with the two CONTRACT differences of the HIP path emulated as well: bf16 P per 64-key flash tile (every
         # flash kernel has that term, the reference's SDPA included) and the merged zero-padding key of the cross-attention
-        ref_c = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True)
-    r, rc = _rel(out, ref), _rel(out, ref_c)
+        taps = {L: None for L in depths}
+        ref_c = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, depth_outputs=taps)
+    r, rc, floor = _rel(out, ref), _rel(out, ref_c), _rel(ref_c, ref)
+    curve = {L: _rel(outs[L], taps[L]) for L in depths}
     mx = (out - ref).abs().max().item()
-    parity("dit_full_depth_30_blocks_N4096", rel_vs_emu_oracle=r, rel_vs_contract_oracle=rc, oracle_contract_vs_exact_softmax=_rel(ref_c, ref),
-           max_abs=mx, ref_rms=ref.pow(2).mean().sqrt().item())
-    print(f"full-depth 30-block N=4096 forward: rel {r:.3e} (exact-softmax oracle), {rc:.3e} (kernel-contract oracle), max abs {mx:.3e}")
+    parity("dit_full_depth_30_blocks_N4096", rel_vs_emu_oracle=r, rel_vs_contract_oracle=rc, oracle_contract_vs_exact_softmax=floor,
+           rel_vs_contract_oracle_by_depth={str(k): v for k, v in curve.items()}, max_abs=mx, ref_rms=ref.pow(2).mean().sqrt().item())
+    print(f"full-depth 30-block N=4096 forward: rel {r:.3e} (exact-softmax oracle), {rc:.3e} (kernel-contract oracle); the two oracles differ "
+          f"by {floor:.3e}; by depth {', '.join(f'{k}: {v:.2e}' for k, v in curve.items())}; max abs {mx:.3e}")
     assert torch.isfinite(out).all()
-    assert r < TOL_FULL_DEPTH_EXACT and rc < TOL_FULL_DEPTH_CONTRACT, (r, rc)
+    # Round 3 finding: HIP, the exact-softmax oracle and the contract oracle are MUTUALLY ~9e-3 apart after 30 blocks - two restatements
+    # of the same arithmetic that differ only in where P is rounded land as far from each other as the kernels land from either.  The
+    # figure is the conditioning of 30 random-weight blocks times the bf16 ulp (error-vs-depth curve: 1e-3 after one block, growing with
+    # depth), not a kernel error; the kernels themselves are pinned at <= 1e-3 of their contract in tests/test_kernels_gpu.py.
+    assert curve[1] < TOL_ONE_BLOCK and curve[2] < 2 * TOL_ONE_BLOCK, curve
+    assert r < TOL_FULL_DEPTH and rc < TOL_FULL_DEPTH, (r, rc)
+    assert rc < 2.0 * floor, (rc, floor)      # no further from the oracle than the oracle's own two forms are from each other (x2)
 
 
 def test_wan14b_width_fp8_attention_matches_e4m3_oracle(hip_lib, parity):
@@ -450,7 +461,7 @@ def test_lora_adapter_forward_matches_unmerged_oracle(hip_lib, parity):
     cfg = dataclasses.replace(WAN_1_3B, text_dim=256, num_layers=2)
     ocfg = O.WanDiTConfig(num_attention_heads=12, attention_head_dim=128, ffn_dim=8960, num_layers=2, text_dim=256, freq_dim=256)
     base = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=21).items()}
-    sd_l, peft = O.with_lora_adapter(base, ocfg, std=0.02)          # |(alpha/r) B A| ~ 3e-3 per entry against |W| ~ 2e-2: a strong adapter
+    sd_l, peft = O.with_lora_adapter(base, ocfg, std=0.05)          # |(alpha/r) B A| ~ 1.4e-2 per entry against |W| ~ 2e-2: a strong adapter
     merged = {k: v.clone() for k, v in base.items()}
     assert merge_lora_into_state_dict(merged, peft, alpha=16, r=8) == 16
     model = WanDiT(cfg, merged, device="cuda")
@@ -469,5 +480,5 @@ def test_lora_adapter_forward_matches_unmerged_oracle(hip_lib, parity):
            oracle_merged_vs_unmerged=gap, adapter_effect_on_output=effect)
     print(f"LoRA forward: HIP(merged) vs oracle(unmerged) {r_u:.2e}, vs oracle(merged) {r_m:.2e}; oracle merged vs unmerged {gap:.2e}; "
           f"adapter moves the output by {effect:.2e}")
-    assert effect > 3e-2                      # the adapter matters, so a dropped or mis-scaled one cannot pass
-    assert r_m < 3e-3 and r_u < 6e-3, (r_m, r_u)
+    assert effect > 10 * r_u                  # the adapter matters, so a dropped or mis-scaled one cannot pass
+    assert r_m < 6e-3 and r_u < 6e-3, (r_m, r_u)
