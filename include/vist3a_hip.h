@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 14) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 15) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -165,6 +165,11 @@ typedef struct {
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 size_t v3a_attention_split_workspace_bytes(int B, int H, int Nq, int D, int kv_split);
+/* Kernel choice for the hd = 128 unbiased, unmasked launch (the DiT self-attention): 0 = automatic, 1 = the 128-query workgroup kernel
+ * (three workgroups per CU), 2 = the 256-query workgroup kernel with one wave per SIMD and 64 queries per wave where the shape allows
+ * it.  Both compute the same arithmetic per query row (bit-identical outputs); the switch exists for A/B timing and the parity tests.
+ * Process-wide; returns the previous value. */
+int v3a_attention_set_kernel(int which);
 
 /* ------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) flash attention forward on the block-scaled MFMA (K = 64, twice the bf16 rate): the self-attention launch of

@@ -40,7 +40,8 @@ def test_forward_with_latent_matches_oracle(hip_lib):
     r_depth = _rel(out.depth_dict["depth"], ora["depth"])
     r_c2w = _rel(out.pred_context_pose["extrinsic"], ora["pred_context_pose"]["extrinsic"])
     print(f"boundary: pose {r_pose:.2e} depth {r_depth:.2e} c2w {r_c2w:.2e} U {out.gaussians.means.shape[1]} vs {ora['gaussians']['means'].shape[1]}")
-    assert r_pose < 4e-2 and r_depth < 2e-2 and r_c2w < 1e-1  # c2w = inverse(w2c) amplifies the bf16-backbone pose noise at width 64
+    assert r_pose < 4e-2 and r_depth < 8e-3 and r_c2w < 1e-1  # measured 2.0e-2 / 4.1e-3 / 5.4e-2 (c2w = inverse(w2c) amplifies the pose noise at width 64;
+    #                                                            at production width: 2.8e-3 / 3.9e-3 / 4.2e-3, tests/test_fullsize_gpu.py)
     assert out.gaussians.means.shape[0] == 1 and out.gaussians.covariances.shape[-2:] == (3, 3) and out.gaussians.harmonics.shape[-2:] == (3, 25)
     U, Uo = out.gaussians.means.shape[1], ora["gaussians"]["means"].shape[1]
     assert abs(U - Uo) <= 0.08 * Uo

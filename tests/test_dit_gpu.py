@@ -52,8 +52,8 @@ def test_forward_matches_oracle(tiny, shape, L):
     assert torch.isfinite(out.float()).all()
     r1, r2 = _rel(out, ref_emu), _rel(out, ref_f32)
     print(f"rel vs emu-oracle {r1:.3e}  vs fp32-oracle {r2:.3e}")
-    assert r1 < 1.5e-2, r1
-    assert r2 < 4e-2, r2
+    assert r1 < 3.4e-3, r1      # measured 1.4e-3 .. 1.7e-3 on MI355X
+    assert r2 < 9.4e-3, r2      # measured 4.7e-3
 
 
 def test_batch2_equals_two_batch1_calls(tiny):
@@ -97,7 +97,7 @@ def test_denoise_loop_matches_oracle_loop(tiny):
         x = sch.step(nz, x)
     r = _rel(out, x)
     print("denoise loop rel", r)
-    assert out.dtype == torch.float32 and r < 3e-2, r
+    assert out.dtype == torch.float32 and r < 1.2e-2, r   # measured 5.9e-3
 
 
 @pytest.mark.parametrize("P,shape", [(2, (2, 16, 2, 16, 16)), (4, (1, 16, 2, 32, 16)), (8, (2, 16, 1, 32, 32))])
@@ -190,7 +190,7 @@ def test_wan14b_width_two_blocks_matches_oracle(hip_lib):
     out = model(lat.cuda(), t.cuda(), text.cuda())[0]
     r = _rel(out, ref)
     print("14B-width rel vs emu-oracle", r)
-    assert torch.isfinite(out.float()).all() and r < 1.5e-2, r
+    assert torch.isfinite(out.float()).all() and r < 1.06e-2, r   # measured 5.3e-3
 
 
 def test_21_view_latent_shapes(tiny):
@@ -202,7 +202,9 @@ def test_21_view_latent_shapes(tiny):
     t = torch.tensor([333, 333])
     ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
     out = model(lat.cuda(), t.cuda(), text.cuda())[0]
-    assert out.shape == lat.shape and _rel(out, ref) < 1.5e-2
+    r = _rel(out, ref)
+    print("21-view tiny rel", r)
+    assert out.shape == lat.shape and r < 3.5e-3, r
 
 
 @pytest.mark.parametrize("Nk", [4096, 512, 1000])
@@ -291,7 +293,7 @@ def test_merged_padding_keys_equal_full_cross_attention(tiny):
     assert any(v[1][5] == 88 and v[1][6] for v in model._ctx.values())  # 80 real rows, padded to a multiple of 8: 88 keys
     assert _rel(a, b) < 2e-3
     ref = O.dit_forward(sd, ocfg, lat.float().cpu(), t.cpu(), text.cpu().to(torch.bfloat16).float(), emulate_bf16=True)
-    assert _rel(a, ref) < 1.5e-2
+    assert _rel(a, ref) < 3.5e-3
     full = (torch.randn(2, 512, ocfg.text_dim, generator=g) * 0.5).cuda()       # nothing to merge
     assert torch.equal(model(lat, t, full)[0], plain(lat, t, full)[0])
     one_pad = full.clone()
@@ -363,7 +365,7 @@ def test_wan14b_width_fp8_attention_matches_e4m3_oracle(hip_lib, parity):
     r, shift = _rel(out8, ref8), _rel(out8, out16)
     parity("dit_14B_width_fp8_attention", rel_vs_e4m3_oracle=r, rel_fp8_mode_vs_bf16_mode=shift)
     print(f"14B-width fp8-attention forward: rel vs e4m3 oracle {r:.2e}; fp8 mode vs bf16 mode {shift:.2e}")
-    assert torch.isfinite(out8.float()).all() and r < 1.5e-2, r
+    assert torch.isfinite(out8.float()).all() and r < 1.26e-2, r   # measured 6.3e-3
 
 
 def test_wan14b_width_fp8_gemm_matches_e4m3_oracle(hip_lib, parity):
@@ -394,7 +396,7 @@ def test_wan14b_width_fp8_gemm_matches_e4m3_oracle(hip_lib, parity):
     # oracle and the forward can only be bounded to a few e-2 here.  The GEMM itself is pinned on identical quantised operands to
     # bf16 rounding (< 1.2e-3, bit-identical across tiles) by tests/test_kernels_gpu.py::test_gemm_fp8_every_tile_matches_e4m3_emulation.
     assert torch.isfinite(outga.float()).all() and r1 < 6e-2 and r2 < 6e-2, (r1, r2)
-    assert shift < 1.5e-1, shift
+    assert shift < 9e-2, shift     # measured 4.6e-2
     # config #4 shards the denoise: per-token quantisation is token-local, so the sequence-parallel forward with e4m3 GEMMs (bf16
     # attention over the gathered slabs) equals the unsharded one bit for bit
     from vist3a_amd.wan.seqpar import ThreadWorld
@@ -481,4 +483,4 @@ def test_lora_adapter_forward_matches_unmerged_oracle(hip_lib, parity):
     print(f"LoRA forward: HIP(merged) vs oracle(unmerged) {r_u:.2e}, vs oracle(merged) {r_m:.2e}; oracle merged vs unmerged {gap:.2e}; "
           f"adapter moves the output by {effect:.2e}")
     assert effect > 10 * r_u                  # the adapter matters, so a dropped or mis-scaled one cannot pass
-    assert r_m < 6e-3 and r_u < 6e-3, (r_m, r_u)
+    assert r_m < 5.4e-3 and r_u < 6.6e-3, (r_m, r_u)   # measured 2.7e-3 / 3.3e-3 (the oracle's own two forms: 3.3e-3 apart)

@@ -183,8 +183,8 @@ def test_gemm_rejects_unknown_flag_bits(hip_lib):
 # vs exact fp32 softmax attention: bounded by the bf16 P operand (2.2-2.4e-3 measured on every shape; every flash kernel incl. the
 # reference's CUDA SDPA has this term).  vs the kernel's own rounding contract (bf16 P emulated): fp32 round-off + the bf16 flips of the
 # output it causes - THIS is the gate that shows whether the kernel computes what it says (north_star: 1e-3).
-TOL_ATTN_EXACT = 4.5e-3
-TOL_ATTN_CONTRACT = 1e-3
+TOL_ATTN_EXACT = 4.5e-3      # measured 1.7e-3 .. 2.36e-3
+TOL_ATTN_CONTRACT = 3e-4     # measured 2e-5 .. 1.5e-4 (north_star asks for 1e-3)
 def _attn_inputs(B, H, Nq, Nk, D, g, scale=1.0):
     q = (torch.randn(B, Nq, H * D, device=dev, generator=g) * scale).to(bf16)
     k = (torch.randn(B, Nk, H * D, device=dev, generator=g) * scale).to(bf16)

@@ -75,14 +75,14 @@ def test_engine_matches_reference_golden(tiny):
         otaps = R.backbone(sd, g["latent"], 1, 2, (28, 28), ocfg.heads, ocfg.n_dino, ocfg.depth)
     tap_err = [_rel(geo["taps"][i].view(2, geo["Pp"], -1)[:, :geo["P"]], t[0]) for i, t in enumerate(otaps)]
     print("backbone tap rel err (bf16 GEMM/attention vs fp32 oracle, width 64):", [f"{e:.1e}" for e in tap_err])
-    assert max(tap_err) < 3e-2
+    assert max(tap_err) < 3e-2      # measured 1.6e-2 (width 64: few channels to average the bf16 noise over)
     poses = torch.stack([p.cpu() for p in out["pred_pose_enc_list"]])[:, None]
     r_pose = _rel(poses, g["pose_enc_list"])
     r_depth = _rel(out["depth"], g["depth"][0, ..., 0])
     r_raw = _rel(out["raw_gs"][:, :84].view(2, 28, 28, 84).permute(0, 3, 1, 2), ora["raw_gs"][0])
     r_pts = _rel(out["pts_all"], ora["pts_all"][0])
     print(f"pose {r_pose:.2e} depth {r_depth:.2e} raw_gs {r_raw:.2e} pts {r_pts:.2e}")
-    assert r_pose < 3e-2 and r_depth < 2e-2 and r_raw < 3e-2 and r_pts < 4e-2
+    assert r_pose < 2.3e-2 and r_depth < 1e-2 and r_raw < 2.1e-2 and r_pts < 3.6e-2   # measured 1.2e-2 / 5.2e-3 / 1.1e-2 / 1.8e-2
     U, Ug = out["gaussians"]["means"].shape[0], g["means"].shape[1]
     print("voxels", U, "reference", Ug)
     assert abs(U - Ug) <= 0.05 * Ug
@@ -116,8 +116,8 @@ def test_engine_multi_head_matches_reference_golden(hip_lib, parity):
     U, Ug = out["gaussians"]["means"].shape[0], g["means"].shape[1]
     parity("recon_multi_head_golden", taps=tap_err, pose=r_pose, depth=r_depth, voxels=U, voxels_reference=Ug)
     print("multi-head golden: taps", [f"{e:.1e}" for e in tap_err], f"pose {r_pose:.2e} depth {r_depth:.2e} voxels {U} vs {Ug}")
-    assert max(tap_err) < 3e-2 and r_pose < 3e-2 and r_depth < 2e-2
-    assert abs(U - Ug) <= 0.05 * Ug
+    assert max(tap_err) < 1.9e-2 and r_pose < 1.7e-2 and r_depth < 4.8e-3   # measured 9.5e-3 / 8.4e-3 / 2.4e-3
+    assert abs(U - Ug) <= 0.06 * Ug    # measured 3 %
 
 
 def test_heads_on_oracle_tokens(tiny):
@@ -137,7 +137,7 @@ def test_heads_on_oracle_tokens(tiny):
     poses = eng.camera(geo, S)
     r = _rel(poses[-1], ora["pred_pose_enc_list"][-1][0])
     print("camera head on oracle tokens:", r)
-    assert r < 1e-4
+    assert r < 1e-6      # fp32 head: measured 1.6e-7
     img = (g["image"][0].permute(1, 2, 3, 0) + 1) / 2
     img_cl = torch.zeros(S, H, W, 8, dtype=torch.bfloat16)
     img_cl[..., :3] = img
@@ -146,7 +146,7 @@ def test_heads_on_oracle_tokens(tiny):
     r_g = _rel(raw_gs[:, :84].view(S, H, W, 84).permute(0, 3, 1, 2), ora["raw_gs"][0])
     r_p = _rel(pts, ora["pts_all"][0])
     print(f"heads on oracle tokens: depth {r_d:.2e} conf {r_c:.2e} raw_gs {r_g:.2e} pts {r_p:.2e}")
-    assert r_d < 1e-2 and r_c < 1e-2 and r_g < 1e-2 and r_p < 1e-2
+    assert r_d < 5e-3 and r_c < 7.2e-3 and r_g < 1.3e-2 and r_p < 1.4e-3    # measured 2.5e-3 / 3.6e-3 / 6.6e-3 / 7.0e-4
     assert torch.allclose(ext.cpu(), ora["extrinsic_w2c"][0], atol=1e-5) and torch.allclose(K.cpu(), ora["intrinsic_px"][0], atol=1e-3)
 
 
@@ -212,7 +212,7 @@ def test_engine_conf_mask_branch_matches_reference_golden(hip_lib):
     dc = out["depth_conf"].float().cpu().reshape(g["depth_conf"].shape)
     rel = ((dc - g["depth_conf"]).norm() / g["depth_conf"].norm()).item()
     print(f"conf-mask branch: kept {K} vs reference {Kref}; depth_conf rel {rel:.2e}")
-    assert rel < 2e-2
+    assert rel < 1.7e-2      # measured 8.3e-3
     assert abs(K - Kref) <= 1     # the kept count is fixed by the quantile (ties aside), whatever the bf16 noise in the values
     mask = (dc > out["conf_valid"].cpu())
     agree = (mask == g["mask"].bool()).float().mean().item()

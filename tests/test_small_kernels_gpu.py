@@ -54,11 +54,11 @@ def test_qknorm_rope2d_multi_head(hip_lib, parity, S, hp, wp, H):
     rq, rk = relerr(got[..., :C], outs[0]), relerr(got[..., C:], outs[1])
     parity("qknorm_rope2d", S=S, hp=hp, wp=wp, heads=H, rel_q=rq, rel_k=rk)
     print(f"qknorm_rope2d S={S} {hp}x{wp} H={H}: q {rq:.2e} k {rk:.2e}")
-    assert rq < 4e-3 and rk < 4e-3     # output is bf16: 2^-9 relative rounding of every element = 2.3e-3 rms
+    assert rq < 3.3e-3 and rk < 3.3e-3     # measured 1.66e-3 = the bf16 rounding of the output itself (every element correctly rounded, below)
     # ... so compare before the final rounding as well: the bf16 result must be the correctly rounded fp32 reference almost everywhere
     exact = (got[..., :C] == outs[0].to(bf16)).float().mean().item()
     parity("qknorm_rope2d_bits", S=S, heads=H, fraction_correctly_rounded=exact)
-    assert exact > 0.995, exact
+    assert exact > 0.999, exact      # measured 1.0
 
 
 @pytest.mark.parametrize("M,d,mode,act", [(13 * 64 * 64, 384, 1, True), (13 * 128 * 128, 192, 1, True), (4 * 512 * 512, 96, 1, True),
@@ -81,7 +81,7 @@ def test_rownorm_act_matches_wan_rms_norm(hip_lib, parity, M, d, mode, act):
     r = relerr(y, ref)
     exact = (y == ref.to(bf16)).float().mean().item()
     parity("rownorm_act", M=M, d=d, mode=mode, silu=act, rel_vs_fp32=r, fraction_correctly_rounded=exact)
-    assert r < 4e-3 and exact > 0.99, (r, exact)
+    assert r < 3.4e-3 and exact > 0.999, (r, exact)    # measured 1.68e-3 (= bf16 output rounding) / 1.0
 
 
 @pytest.mark.parametrize("M,N,scale", [(4096, 4096, 384 ** -0.5), (1000, 1024, 0.05), (3, 8, 1.0)])
@@ -95,7 +95,7 @@ def test_softmax_rows_matches_torch(hip_lib, parity, M, N, scale):
     r = relerr(p, ref)
     rows = (p.float().sum(-1) - 1).abs().max().item()
     parity("softmax_rows", M=M, N=N, rel_vs_fp32=r, max_row_sum_error=rows)
-    assert r < 4e-3 and rows < 2e-2, (r, rows)
+    assert r < 3.2e-3 and rows < 2.7e-3, (r, rows)     # measured 1.6e-3 / 1.3e-3
 
 
 def test_depth_unproject_matches_geometry(hip_lib, parity):
@@ -118,7 +118,7 @@ def test_depth_unproject_matches_geometry(hip_lib, parity):
     rd, rc, rp = relerr(depth.cpu(), depth_ref[0]), relerr(conf.cpu(), (1 + raw[:, 1].exp()).view(S, H, W)), relerr(pts.cpu(), pts_ref)
     parity("depth_unproject", S=S, H=H, W=W, rel_depth=rd, rel_conf=rc, rel_pts=rp)
     print(f"depth_unproject: depth {rd:.1e} conf {rc:.1e} pts {rp:.1e}")
-    assert rd < 1e-6 and rc < 1e-6 and rp < 2e-6, (rd, rc, rp)
+    assert rd < 5e-8 and rc < 4e-8 and rp < 1.6e-7, (rd, rc, rp)    # measured 2.2e-8 / 1.7e-8 / 8.0e-8
     assert torch.allclose(e2.cpu(), ext[0], atol=1e-6) and torch.allclose(K2.cpu(), K[0], rtol=1e-6)
 
 
@@ -143,7 +143,7 @@ def test_linear_f32_matches_torch(hip_lib, parity, M, N, K, act, extra):
         ref = res.double() + gam.double() * ref
     r = relerr(y.double(), ref)
     parity("linear_f32", M=M, N=N, K=K, act=act, ls_residual=extra, rel_vs_fp64=r)
-    assert r < 2e-6, r
+    assert r < 4e-7, r       # measured 4e-8 .. 2e-7
 
 
 @pytest.mark.parametrize("S,H", [(13, 16), (21, 16), (2, 4), (32, 16)])
@@ -157,4 +157,4 @@ def test_attention_small_f32_matches_sdpa(hip_lib, parity, S, H):
     ref = (torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v).permute(1, 0, 2).reshape(S, H * hd)
     r = relerr(out.double(), ref)
     parity("attention_small_f32", S=S, H=H, rel_vs_fp64=r)
-    assert r < 2e-6, r
+    assert r < 6e-7, r       # measured 1.3e-7 .. 3.0e-7

@@ -76,7 +76,7 @@ def test_encoder_lengths_and_production_width(hip_lib, n):
     ref = OU.prompt_embeds(sd, OU.UMT5Config(**kw), ids, mask, 512)
     r = _rel(out, ref)
     print("umt5 prod-width rel", n, r)
-    assert r < 1e-2 and float(out[0, n:].abs().sum()) == 0
+    assert r < 8.6e-3 and float(out[0, n:].abs().sum()) == 0     # measured 2.8e-3 .. 4.3e-3
 
 
 def test_mask_must_be_right_padded_and_pipeline_adapter(hip_lib):

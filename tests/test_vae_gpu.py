@@ -28,7 +28,7 @@ def test_decode_matches_reference_golden(hip_lib):
     assert out.shape == g["out"].shape and out.dtype == torch.bfloat16
     r = _rel(out, g["out"])
     print("vae golden rel", r)
-    assert r < 2e-2, r
+    assert r < 2.8e-2, r     # measured 1.4e-2
 
 
 @pytest.mark.parametrize("T,hw", [(1, 8), (2, 16), (4, 8)])

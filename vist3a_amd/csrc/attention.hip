@@ -359,6 +359,261 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 3: the DiT self-attention (hd = 128, no bias / mask) with ONE wave per SIMD and 64 queries per wave.
+//   * a workgroup = 4 waves = 256 queries; every K / V^T tile in LDS serves 256 queries (half the LDS-DMA pieces per query of the
+//     128-query kernel above) and every fragment read from LDS feeds two MFMAs (two 32-query blocks A and B per wave);
+//   * register files are assigned by hand through inline-asm operand classes, because hipcc left to itself shuttles MFMA results
+//     between the two files (measured on the QB = 2 instantiation of the kernel above: ~480 v_accvgpr moves per 64 MFMAs):
+//       O^T accumulators (128 registers) and the Q fragments (64) live in the ACCUMULATOR file for the whole kernel,
+//       S^T (64), P (32), the K / V^T fragments in flight and the softmax temporaries in the architectural VGPRs;
+//   * MFMAs are asm statements, so hipcc neither pads their result hazards nor moves them: the `mfma_fence` statements below carry the
+//     wait states an MFMA result needs before a VALU instruction may read it (8-pass XDL op: 12 states; two s_nop 15 are issued).
+// Same arithmetic per query row as attn_fwd_kernel (same ascending-k MFMA chains, same per-32-row rescale decision): bit-identical.
+__device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a, const bf16x8& b) {   // d = a . b          (S^T, first k step)
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8& b) {    // d += a . b         (S^T in VGPRs, Q in AGPRs)
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_o(f32x16& d, const bf16x8& a, const bf16x8& b) {    // d += a . b         (O^T in AGPRs)
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+}
+// LDS-DMA that hipcc does not see: behind the builtin it orders the next LDS read after the copy (s_waitcnt vmcnt(0) straight after
+// the issue - with one wave per SIMD that puts the whole L2 latency of every tile on the critical path).  Here the copy is counted by
+// the explicit s_waitcnt vmcnt at the end of the tile.  M0 = wave-uniform LDS byte address of the 1 KB piece (lane i lands at +16 i).
+__device__ __forceinline__ void glds16_raw(const void* gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void mfma_fence_v(f32x16& a, f32x16& b) {   // MFMA results in VGPRs -> VALU readers
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void mfma_fence_a(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {   // MFMA results in AGPRs -> v_accvgpr_read
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a), "+a"(b), "+a"(c), "+a"(d));
+}
+
+// online softmax of one 32-query block over one 64-key tile: S^T (two 32-key sub-tiles) -> P fragments; returns the rescale factor
+// (1 when the exponent reference did not move).  Identical to the in-line code of attn_fwd_kernel.
+__device__ __forceinline__ bool softmax_block(const f32x16& s0, const f32x16& s1, float c, float& m_run, float& l_run, bf16x8 (&pf)[4],
+                                              float& alpha) {
+  constexpr float DEFER = 8.0f;
+  float mx = s0[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m_new = fmaxf(m_run, mx);
+  const bool rescale = __builtin_amdgcn_ballot_w64((m_new - m_run) * c > DEFER) != 0;
+  alpha = 1.0f;
+  if (rescale) {
+    alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    m_run = m_new;
+  }
+  const float mc = m_run * c;
+  float psum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pv[r] = __builtin_amdgcn_exp2f((t ? s1[r] : s0[r]) * c - mc);
+      psum += pv[r];
+    }
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      u32x4 pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // a VECTOR fptrunc: selected as one v_cvt_pk_bf16_f32 (two scalar casts became 2 x cvt + v_perm here)
+        const f32x2 pr = {pv[8 * ks2 + 2 * e], pv[8 * ks2 + 2 * e + 1]};
+        pk[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(pr, v3a_bf16x2));
+      }
+      pf[2 * t + ks2] = __builtin_bit_cast(bf16x8, pk);
+    }
+  }
+  l_run = l_run * alpha + psum;
+  return rescale;
+}
+
+__global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const AttnP p) {
+  constexpr int D = 128, NW = 4, KV = 64, KROWB = 256, KTILE = KV * KROWB, VTILE = D * 128, STAGE = KTILE + VTILE;
+  constexpr int KINS = KTILE / 1024 / NW, VINS = VTILE / 1024 / NW, KS = 8, DT = 4, OPITCH = D * 2 + 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int nqb = (p.Nq + 255) / 256;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = bid / nqb, qb = bid % nqb;
+  const int b = bh / p.H, h = bh % p.H;
+  const int q0 = qb * 256 + wave * 64;
+  const char* Qb = p.q + ((size_t)b * p.q_bs + (size_t)h * D) * 2;
+  const char* Kb = p.k + ((size_t)b * p.k_bs + (size_t)h * D) * 2;
+  const char* Vb = p.vt + ((size_t)h * D * p.ldvt + (size_t)b * p.vt_bs) * 2;
+
+  bf16x8 qf[2][KS];
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    int qr = q0 + qq * 32 + l31;
+    qr = qr < p.Nq ? qr : p.Nq - 1;
+    const char* qp = Qb + (size_t)qr * p.ldq * 2 + hi * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[qq][ks] = *(const bf16x8*)(qp + ks * 32);
+  }
+  // DMA sources (same LDS image and swizzles as attn_fwd_kernel at hd = 128)
+  const char* kp[KINS];
+  const char* vp[VINS];
+#pragma unroll
+  for (int j = 0; j < KINS; ++j) {
+    const int r = (j * NW + wave) * 4 + lane / 16, cch = lane % 16;
+    kp[j] = Kb + (size_t)r * p.ldk * 2 + (size_t)(cch ^ (r & 15)) * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < VINS; ++j) {
+    const int r = (j * NW + wave) * 8 + (lane >> 3);
+    const int cch = (lane & 7) ^ ((r >> 1) & 7);
+    vp[j] = Vb + ((size_t)r * p.ldvt + cch * 8) * 2;
+  }
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(LDS_AS char*)smem);
+  auto stage = [&](int s, int kt) {
+    const unsigned sb = lds0 + s * STAGE + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < KINS; ++j) glds16_raw(kp[j] + (size_t)kt * KV * p.ldk * 2, sb + j * NW * 1024);
+#pragma unroll
+    for (int j = 0; j < VINS; ++j) glds16_raw(vp[j] + (size_t)kt * KV * 2, sb + KTILE + j * NW * 1024);
+  };
+  const int pi = (l31 & 3) + 4 * (l31 >> 3) + 16 * ((l31 >> 2) & 1);
+  int kfo[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kfo[ks] = pi * KROWB + (((2 * ks + hi) ^ (pi & 15)) << 4);
+  int vfo[4];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) vfo[c4] = l31 * 128 + (((4 * (c4 >> 1) + 2 * hi + (c4 & 1)) ^ ((l31 >> 1) & 7)) << 4);
+
+  f32x16 oa[DT], ob[DT];    // O^T of q-block A / B
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oa[i][r] = 0.f; ob[i][r] = 0.f; }
+  float ma = -1e30f, mb = -1e30f, la = 0.f, lb = 0.f;
+  const float c = p.scale_log2e;
+  const int nkt = p.Nk / KV;
+
+  stage(0, 0);
+  // a wait hipcc SEES (the builtin, not an asm string): it retires the Q loads in the compiler's own bookkeeping - otherwise every
+  // first use of a Q register inside the loop gets a compiler-inserted s_waitcnt vmcnt(7..0) that drains the hidden LDS-DMA stream
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    const char* sK = smem + cur * STAGE;
+    const char* sV = sK + KTILE;
+    f32x16 sa0, sa1, sb0, sb1;
+    {   // S^T = K . Q^T: 16 K fragments (2 sub-tiles x 8 k steps), each feeding both q-blocks; fragment reads run two ahead of their MFMAs
+        // (the MFMA statements are volatile asm: hipcc does not move LDS reads across them, so the distance is set here)
+      bf16x8 kf[16];
+      auto ldk = [&](int j) { return *(const bf16x8*)(sK + (j >> 3) * 32 * KROWB + kfo[j & 7]); };
+      kf[0] = ldk(0);
+      kf[1] = ldk(1);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j + 2 < 16) kf[j + 2] = ldk(j + 2);
+        f32x16& xa = (j >> 3) ? sa1 : sa0;
+        f32x16& xb = (j >> 3) ? sb1 : sb0;
+        if ((j & 7) == 0) { mfma_s0(xa, kf[j], qf[0][0]); mfma_s0(xb, kf[j], qf[1][0]); }
+        else { mfma_s(xa, kf[j], qf[0][j & 7]); mfma_s(xb, kf[j], qf[1][j & 7]); }
+      }
+    }
+    mfma_fence_v(sa0, sa1);
+    mfma_fence_v(sb0, sb1);
+    bf16x8 pa[4], pb[4];
+    float al;
+    if (softmax_block(sa0, sa1, c, ma, la, pa, al)) {
+      mfma_fence_a(oa[0], oa[1], oa[2], oa[3]);
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[i][r] *= al;
+    }
+    if (softmax_block(sb0, sb1, c, mb, lb, pb, al)) {
+      mfma_fence_a(ob[0], ob[1], ob[2], ob[3]);
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[i][r] *= al;
+    }
+    {   // O^T += V^T . P^T: 16 V^T fragments (4 key chunks x 4 d tiles), each feeding both q-blocks, reads two ahead
+      bf16x8 vf[16];
+      auto ldv = [&](int j) { return *(const bf16x8*)(sV + (j & 3) * 4096 + vfo[j >> 2]); };
+      vf[0] = ldv(0);
+      vf[1] = ldv(1);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (j + 2 < 16) vf[j + 2] = ldv(j + 2);
+        if ((j & 3) == 0) asm volatile("s_nop 1" : "+v"(pa[j >> 2]), "+v"(pb[j >> 2]));   // VALU-written P -> MFMA operand
+        mfma_o(oa[j & 3], vf[j], pa[j >> 2]);
+        mfma_o(ob[j & 3], vf[j], pb[j >> 2]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  mfma_fence_a(oa[0], oa[1], oa[2], oa[3]);
+  mfma_fence_a(ob[0], ob[1], ob[2], ob[3]);
+  char* reg = smem + wave * (32 * OPITCH);
+  char* Ob = p.o + ((size_t)b * p.o_bs + (size_t)h * D) * 2;
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    const float lx = qq ? lb : la;
+    const float inv = 1.0f / (lx + __shfl_xor(lx, 32, 64));
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      const f32x16& o = qq ? ob[i] : oa[i];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2 pk;
+        pk[0] = pack_bf16x2(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
+        pk[1] = pack_bf16x2(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
+        *(u32x2*)(reg + l31 * OPITCH + (i * 32 + g * 8 + hi * 4) * 2) = pk;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * 64 + lane;
+      const int ql = idx / 16, ch = idx % 16;
+      const u32x2 lo = *(const u32x2*)(reg + ql * OPITCH + ch * 16);
+      const u32x2 hi2 = *(const u32x2*)(reg + ql * OPITCH + ch * 16 + 8);
+      const int qr = q0 + qq * 32 + ql;
+      if (qr < p.Nq) {
+        u32x4 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = hi2[0]; v[3] = hi2[1];
+        *(u32x4*)(Ob + ((size_t)qr * p.ldo) * 2 + ch * 16) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+int launch_attn64(const AttnP& p, int B, void* stream) {
+  constexpr int LDS = 2 * (64 * 256 + 128 * 128);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)attn_fwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return V3A_ERR_LAUNCH;
+    attr = true;
+  }
+  const int nqb = (p.Nq + 255) / 256;
+  hipLaunchKernelGGL(attn_fwd64_kernel, dim3((unsigned)(nqb * B * p.H)), dim3(256), LDS, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
+}
+
 // Finish a key-split attention: one wave per (batch, query, head) merges the S partial softmaxes,
 //   O = sum_s 2^((m_s - M) c) O_s / sum_s 2^((m_s - M) c) l_s,   M = max_s m_s,
 // in a fixed order (deterministic), and writes the bf16 row.
@@ -431,6 +686,13 @@ int v3a_attn_combine_launch(const float* ws_o, const float* ws_ml, void* o, long
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
+static int g_attn_kernel = 0;
+extern "C" int v3a_attention_set_kernel(int which) {
+  const int prev = g_attn_kernel;
+  if (which >= 0 && which <= 2) g_attn_kernel = which;
+  return prev;
+}
+
 extern "C" size_t v3a_attention_split_workspace_bytes(int B, int H, int Nq, int D, int kv_split) {
   if (B <= 0 || H <= 0 || Nq <= 0 || D <= 0 || kv_split <= 1) return 0;
   return (size_t)kv_split * B * Nq * H * (D + 2) * sizeof(float);
@@ -478,6 +740,9 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
     return launch_attn<128, 4, false, true, true>(p, a->B, stream);
   }
   if (a->D == 128) {
+    static const bool pw64_env = getenv("V3A_ATTN_PW64") != nullptr;   // experiment switch: one wave per SIMD, 64 queries per wave
+    const bool pw64 = g_attn_kernel == 2 || (g_attn_kernel == 0 && pw64_env);
+    if (pw64 && p.kv_split == 1 && !a->kv_seg && a->Nk % 64 == 0 && !a->kv_period && a->Nq >= 256) return launch_attn64(p, a->B, stream);
     if (two_per_cu) return launch_attn<128, 4, false, false, false>(p, a->B, stream);
     // a sequence-parallel shard (Nq = N / P queries against all N keys) has too few 128-query blocks to occupy 256 CUs: 64-query
     // workgroups double the count; per-wave arithmetic and key order are unchanged, so the output stays bit-identical

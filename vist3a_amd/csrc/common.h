@@ -8,6 +8,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(8))) int i32x8;         // 32 e4m3 = one 32x32x64 f8f6f4 MFMA A/B fragment (8 VGPR)

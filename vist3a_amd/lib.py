@@ -164,6 +164,7 @@ SYMBOLS = {
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "v3a_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "v3a_attention_set_kernel": (C.c_int, [C.c_int]),
     "v3a_attention_fwd_fp8": (C.c_int, [C.POINTER(AttnFp8Args), C.c_void_p]),
     "v3a_gemm_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "v3a_gemm_pick_tile_act": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -198,7 +199,7 @@ SYMBOLS = {
 }
 
 _lib = None
-EXPECTED_ABI = 14   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
+EXPECTED_ABI = 15   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
 
 
 class HipLibraryError(RuntimeError):
