@@ -165,10 +165,9 @@ typedef struct {
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 size_t v3a_attention_split_workspace_bytes(int B, int H, int Nq, int D, int kv_split);
-/* Kernel choice for the hd = 128 unbiased, unmasked launch (the DiT self-attention): 0 = automatic, 1 = the 128-query workgroup kernel
- * (three workgroups per CU), 2 = the 256-query workgroup kernel with one wave per SIMD and 64 queries per wave where the shape allows
- * it.  Both compute the same arithmetic per query row (bit-identical outputs); the switch exists for A/B timing and the parity tests.
- * Process-wide; returns the previous value. */
+/* Experiment switch for the hd = 128 unbiased, unmasked launch (the DiT self-attention): 0 / 1 = the production kernel (128-query
+ * workgroups, three per CU); 2 / 3 = the one-wave-per-SIMD study kernels, which exist only in builds with -DV3A_ATTN_EXPERIMENTAL
+ * (tools/abl_build.sh) and are ignored otherwise.  Process-wide; returns the previous value. */
 int v3a_attention_set_kernel(int which);
 
 /* ------------------------------------------------------------------------------------------------

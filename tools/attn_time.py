@@ -18,7 +18,7 @@ for B, H, N in shapes:
     for b in range(B):
         vt[:, b * N:(b + 1) * N] = v[b * N:(b + 1) * N].t()
     outs = {}
-    for which in (1, 2):
+    for which in (1, 2, 3):
         L.v3a_attention_set_kernel(which)
         o = torch.empty(B * N, d, device="cuda", dtype=torch.bfloat16)
         run = lambda: ops.attention(q, k, vt, o, B=B, H=H, Nq=N, Nk=N, D=D, q_batch_stride=N * d, k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=N * d)
@@ -38,5 +38,5 @@ for B, H, N in shapes:
         outs[which] = o.clone()
         print(json.dumps(dict(B=B, H=H, N=N, kernel=which, us=round(us, 1), rounds_us=times, tflops=round(4 * B * H * N * N * D / us / 1e6), rel=rel)), flush=True)
     L.v3a_attention_set_kernel(0)
-    print(json.dumps(dict(B=B, H=H, N=N, bit_identical=bool(torch.equal(outs[1], outs[2])),
-                          max_abs_diff=(outs[1].float() - outs[2].float()).abs().max().item())), flush=True)
+    print(json.dumps(dict(B=B, H=H, N=N, bit_identical_2=bool(torch.equal(outs[1], outs[2])), bit_identical_3=bool(torch.equal(outs[1], outs[3])),
+                          max_abs_diff_3=(outs[1].float() - outs[3].float()).abs().max().item())), flush=True)
