@@ -23,24 +23,32 @@ if str(ROOT) not in sys.path:
 
 import torch
 
+# tile name (v3a_gemm_tile_name) -> kernel symbol as rocprofv3 prints it
+SYMBOL_OF_TILE = {"pp_np3_ratrue_l5": "gemm_pp_kernel<3, true, 5, 0, false>", "pp_np3_rafalse_l5": "gemm_pp_kernel<3, false, 5, 0, false>",
+                  "pp_np4_ratrue_l7": "gemm_pp_kernel<4, true, 7, 0, false>"}
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FP8_MFMA_PEAK_TFLOPS = 5000.0   # dense fp8 (--dtype fp8 only)
 
 
-def pmc_traffic(kernel_key: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*/pmc_traffic.json, produced by
+def pmc_traffic(kernel_symbol: str):
+    """HBM bytes per launch of the dominant kernel from the LATEST committed PMC pass (profiles/rNN/pmc_traffic.json, produced by
     tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied).  bench.py cannot run rocprofv3
-    around itself, so this is the value of the same command profiled at round time; null if the file is absent."""
-    best = None
-    for f in sorted(ROOT.glob("profiles/*/pmc_traffic.json")):
-        try:
-            k = json.loads(f.read_text())["kernels"]
-            for name, v in k.items():
-                if name.replace(" ", "").startswith(kernel_key.replace(" ", "")):
-                    best = v["hbm_bytes_per_launch"]
-        except Exception:  # noqa: BLE001
-            pass
-    return best
+    around itself, so this is the value of the same command profiled at round time.  Returns (bytes, source file) - and (None, reason)
+    when the newest file does not carry exactly the symbol this run's dominant tile resolves to: a stale figure for another tile must
+    not be printed beside a new kernel."""
+    files = sorted(ROOT.glob("profiles/r*/pmc_traffic.json"), key=lambda f: int("".join(c for c in f.parent.name if c.isdigit()) or 0))
+    if not files:
+        return None, "no profiles/rNN/pmc_traffic.json"
+    f = files[-1]
+    try:
+        k = json.loads(f.read_text())["kernels"]
+    except Exception as e:  # noqa: BLE001
+        return None, f"{f}: {e}"
+    want = kernel_symbol.replace(" ", "")
+    for name, v in k.items():
+        if name.replace(" ", "") == want:
+            return v["hbm_bytes_per_launch"], str(f.relative_to(ROOT))
+    return None, f"{f.relative_to(ROOT)} holds no row for {kernel_symbol} (profiled before the dominant tile changed: re-run tools/pmc_traffic.sh)"
 
 
 def dit_flops_per_forward(N, d, ffn, L, ctx=512):
@@ -48,8 +56,11 @@ def dit_flops_per_forward(N, d, ffn, L, ctx=512):
     return L * (8 * N * d * d + 4 * N * N * d + (4 * N * d * d + 4 * ctx * d * d) + 4 * N * ctx * d + 4 * N * d * ffn)
 
 
-def cpu_baseline(cfg, mode: str):
-    """The CPU oracle (fp32 restatement of the reference path, `kind: "port"`) timed ONCE on this host's cores, stage by stage, at
+def cpu_baseline(cfg, mode: str, repeats: int = 3, dit_blocks: int = 6):
+    """The CPU oracle (fp32 restatement of the reference path, `kind: "port"`) timed on this host's cores, stage by stage.  The DiT
+    forward is 97 % of a scene's CPU time, and single shots of it swung 1.7x between boxes: it is timed `repeats` times on a BOUNDED
+    sample - the full-size forward truncated to `dit_blocks` of its 30 identical blocks - and the minimum is scaled by 30 / dit_blocks
+    (patchify / head are < 0.1 %).  VAE decode and reconstruction (3 % together) are single full-size shots.  All at
     the production shapes of config #1/#2: one full 30-block DiT forward (N = 4096 tokens, B = 1), one Wan VAE
     decode (latent [1,16,4,64,64] -> 13 x 512^2) and one stitched reconstruction forward (13 views @448, 22 DINO + 48 aggregator
     blocks at width 1024, heads, voxel fusion).  A scene is 2 x steps DiT forwards + one decode + one reconstruction: only that
@@ -65,39 +76,43 @@ def cpu_baseline(cfg, mode: str):
     lat = torch.randn(1, 16, 4, 64, 64, generator=g)
     text = torch.randn(1, 512, cfg.text_dim, generator=g) * 0.1
     t = torch.tensor([900])
-    stages = {}
+    stages, runs = {}, {}
+
+    def timed(name, fn, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        stages[name], runs[name] = min(ts), [round(x, 2) for x in ts]
+        return r
+
     with torch.no_grad():
         O.dit_forward(sd, ocfg, lat[:, :, :1, :16, :16], t, text, num_layers=1)  # warm the thread pool on a small clip
-        t0 = time.perf_counter()
-        O.dit_forward(sd, ocfg, lat, t, text)
-        stages["dit_forward_s"] = time.perf_counter() - t0
+        nb = min(dit_blocks, cfg.num_layers)
+        timed("dit_sample_s", lambda: O.dit_forward(sd, ocfg, lat, t, text, num_layers=nb), repeats)
+        stages["dit_forward_s"] = stages["dit_sample_s"] * cfg.num_layers / nb
         del sd
         if mode == "full":
             vcfg = V.WanVAEConfig()
             vsd = V.make_weights(vcfg, seed=1)
-            t0 = time.perf_counter()
-            img = V.decode(vsd, vcfg, lat)
-            stages["vae_decode_s"] = time.perf_counter() - t0
+            img = timed("vae_decode_s", lambda: V.decode(vsd, vcfg, lat), 1)
             del vsd
             rcfg = R.ReconCfg()
             rsd = R.make_recon_weights(rcfg, seed=2)
             w = torch.randn(rcfg.C, 16, 5, 3, 3, generator=g) * 0.02
             img448 = torch.nn.functional.interpolate(img[0].permute(1, 0, 2, 3).clamp(-1, 1), size=(448, 448), mode="bilinear", align_corners=False)
             img448 = img448.permute(1, 0, 2, 3)[None]
-            t0 = time.perf_counter()
-            feat = R.stitch_conv(R.upsample_T(lat), w, torch.zeros(rcfg.C), (1, 2, 2), (2, 1, 1))
-            R.recon_forward(rsd, rcfg, feat, img448)
-            stages["stitch_recon_s"] = time.perf_counter() - t0
+            timed("stitch_recon_s", lambda: R.recon_forward(rsd, rcfg, R.stitch_conv(R.upsample_T(lat), w, torch.zeros(rcfg.C), (1, 2, 2), (2, 1, 1)), img448), 1)
             del rsd
     tail = stages.get("vae_decode_s", 0.0) + stages.get("stitch_recon_s", 0.0)
     scene50 = 100 * stages["dit_forward_s"] + tail
     scene10 = 20 * stages["dit_forward_s"] + tail
-    what = ("one full DiT forward + one VAE decode + one reconstruction forward" if mode == "full" else
-            "one full DiT forward; VAE decode + reconstruction (5 % of the FLOPs) not timed")
+    what = (f"DiT: min of {repeats} runs of {nb} of {cfg.num_layers} blocks at full size, x {cfg.num_layers}/{nb}; "
+            + ("one VAE decode + one reconstruction forward, single shots" if mode == "full" else "VAE decode + reconstruction (3 % of the time) not timed"))
     return dict(value=1.0 / scene50, unit="scenes/s", cores=n, kind="port",
-                sample=f"oracle fp32 on {n} threads, production shapes, each stage timed once: {what}; scene = 100 x DiT + decode + recon "
-                       f"(only the x100 is extrapolated)",
-                stage_seconds={k: round(v, 2) for k, v in stages.items()},
+                sample=f"oracle fp32 on {n} threads, production shapes ({what}); scene = 100 x DiT forward + decode + recon",
+                stage_seconds={k: round(v, 2) for k, v in stages.items()}, stage_runs_seconds=runs,
                 scene_seconds_50_steps=round(scene50, 1),
                 config1_10_steps={"scene_seconds": round(scene10, 1), "scenes_per_s": 1.0 / scene10,
                                   "note": "BASELINE config #1 (10 denoise steps) = 20 x DiT + decode + recon"})
@@ -198,10 +213,34 @@ def main():
     dt = time.perf_counter() - t0
     probe.active = False
     ops.set_gemm_probe(None)
+    per_rank = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        # every rank's wall time and stage times of its last scene (not part of the timed region): shows WHICH stage or rank is slow
+        mine = torch.tensor([dt, stage.denoise_ms, stage.vae_ms, stage.recon_ms], device=dev, dtype=torch.float64)
+        allr = torch.empty(world, 4, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr.view(-1), mine)
+        per_rank = [{"rank": r, "wall_s": round(v[0], 3), "denoise_ms": round(v[1], 1), "vae_ms": round(v[2], 1), "recon_ms": round(v[3], 1)}
+                    for r, v in enumerate(allr.cpu().tolist())]
         dt = tt.item()
+    comm = None
+    if coop:
+        # RCCL time of the sequence-parallel all-gathers on their own: two extra denoise steps, untimed, with every all-gather run
+        # synchronously between events (in the timed region they overlap the Q projection)
+        plan = model.pipe.plan
+        groups = [g for g in (plan.sp, plan.cfg) if g is not None]
+        for g in groups:
+            g.profile = True
+        gq = torch.Generator().manual_seed(1)
+        model.generate(pe, ne, latents=torch.randn(1, 16, Tl, 64, 64, generator=gq), num_frames=a.num_frames, num_inference_steps=2, guidance_scale=7.5)
+        names = [n for n, g in (("sequence_parallel_kv", plan.sp), ("cfg_pair_noise", plan.cfg)) if g is not None]
+        comm = {n: g.profile_summary() for n, g in zip(names, groups)}
+        for n in comm:
+            comm[n] = {"calls_per_step": comm[n]["calls"] // 2, "ms_per_step": round(comm[n]["ms"] / 2, 3),
+                       "gathered_MB_per_step": round(comm[n]["gathered_bytes"] / 2 / 1e6, 2)}
+        for g in groups:
+            g.profile = False
     # the step after the path, reported beside the metric, never inside it: orbit render of the last scene
     render_ms = None
     if rank == 0:
@@ -249,6 +288,8 @@ def main():
         fwd_flops = dit_flops_per_forward(N, cfg.dim, cfg.ffn_dim, cfg.num_layers)
         ctx_keys = (64 + 1 + 80 + 1) // 2   # synthetic prompts: 64 / 80 real tokens + one merged padding key each (cond / uncond)
         U = int(out.gaussians.means.shape[1])
+        dom_symbol = SYMBOL_OF_TILE.get(lib.load().v3a_gemm_tile_name(dom_tile).decode()) if not f8 else None
+        traffic, traffic_src = (None, "fp8 mode: not profiled") if f8 else (pmc_traffic(dom_symbol) if dom_symbol else (None, "unknown tile symbol"))
         line = {
             "metric": "3D Gaussian scenes/sec (50-step denoise, 512^2, 13 views)",
             "value": (1 if coop else world) * a.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -260,6 +301,14 @@ def main():
                                    "VAE decode, 448^2 AnySplat enc_blocks_2 reconstruction with voxel fusion; "
                                    + ("one scene over all GPUs (CFG-parallel x sequence-parallel)" if coop else "1 prompt per GPU (data parallel)"),
                        "denoise_steps": a.denoise_steps, "views": a.num_frames, "dit_tokens": N, "gaussians_last_scene": U,
+                       **({"per_rank_last_scene": per_rank} if per_rank else {}),
+                       **({"scene_parallel": {
+                           "layout": dict(zip(("cfg_degree", "sp_degree"), DenoisePlan.layout(world))),
+                           "sp_mode": ("exact (sp_kv_split = 1): bit-identical to the single-GPU forward" if model.transformer.sp_kv_split == 1 else
+                                       "default (sp_kv_split = None): key-split attention + split-K FFN2 on the shards - deterministic, within bf16 "
+                                       "rounding (5e-3) of the single-GPU forward, NOT bit-identical"),
+                           "graph": "eager (the sharded forward is not captured: RCCL collectives inside a hipGraph are untested on this pool)",
+                           "rccl_all_gather (2 untimed profiled steps, collectives serialised)": comm}} if coop else {}),
                        "stage_ms_last_scene": {"denoise": round(stage.denoise_ms, 1), "vae_decode+resize": round(stage.vae_ms, 1),
                                                "stitch+recon": round(stage.recon_ms, 1)},
                        "orbit_render_ms_132_cameras_448 (untimed extra)": round(render_ms, 1),
@@ -271,10 +320,10 @@ def main():
                                          f"{ctx_keys} cross-attention keys after merging the zero-padding keys, context K/V cached per prompt"},
             "roofline": {"bound": "mfma",
                          "kernel": (f"gemm_pp_kernel<.., F8> = tile {lib.load().v3a_gemm_fp8_tile_name(dom_tile).decode()} (e4m3 MFMA 32x32x64 f8f6f4, ping-pong)" if f8 else
-                                    f"gemm_pp_kernel<3, true, 5, 0> = tile {lib.load().v3a_gemm_tile_name(dom_tile).decode()} (bf16 MFMA 32x32x16, ping-pong 256x192)"),
+                                    f"{dom_symbol} = tile {lib.load().v3a_gemm_tile_name(dom_tile).decode()} (bf16 MFMA 32x32x16, ping-pong 256x192)"),
                          "achieved": round(ach, 1), "peak": FP8_MFMA_PEAK_TFLOPS if f8 else BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / (FP8_MFMA_PEAK_TFLOPS if f8 else BF16_MFMA_PEAK_TFLOPS), 4),
-                         "traffic": None if f8 else pmc_traffic("gemm_pp_kernel<3,true"), "traffic_unit": "bytes/launch (PMC, profiles/)",
+                         "traffic": traffic, "traffic_unit": "bytes/launch (PMC FETCH_SIZE + WRITE_SIZE of this symbol)", "traffic_source": traffic_src,
                          "launches_timed": ps["launches"], "launch_sampling": "every 7th launch of the symbol in the last timed scene", "avg_launch_ms": round(ps["avg_ms"], 4),
                          "flops_per_launch": ps["flops_per_launch"]},
         }

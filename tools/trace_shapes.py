@@ -9,4 +9,5 @@ for r in csv.DictReader(open(f)):
 tot = sum(sum(v) for v in acc.values())
 for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[: int(sys.argv[2]) if len(sys.argv) > 2 else 20]:
     v2 = sorted(v)[len(v) // 10: len(v) - len(v) // 10] or v
-    print(f"{k[0]:50s} grid {k[1]:>8s} n {len(v):5d} avg_us {sum(v2) / len(v2):9.1f} share {100 * sum(v) / tot:5.1f}%")
+    # avg_us is the TRUE mean (what a roofline needs: total time / launches); trim_us drops the top and bottom 10 % (cold first launches)
+    print(f"{k[0]:50s} grid {k[1]:>8s} n {len(v):5d} avg_us {sum(v) / len(v):9.1f} trim_us {sum(v2) / len(v2):9.1f} share {100 * sum(v) / tot:5.1f}%")

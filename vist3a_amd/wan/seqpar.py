@@ -36,11 +36,30 @@ class DistGroup:
 
     def __init__(self, ranks: List[int], my_global_rank: int, pg):
         self.ranks, self.world, self.rank, self.pg = list(ranks), len(ranks), list(ranks).index(my_global_rank), pg
+        # measurement mode (bench.py --parallel scene, AFTER its timed region): every all-gather runs synchronously between two events
+        # on the current stream, so its own duration is seen without the compute it normally hides under
+        self.profile = False
+        self.events: List[tuple] = []
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         """out [P, n] <- every rank's inp [n]; asynchronous: returns a handle whose wait() orders the current stream."""
         import torch.distributed as dist
+        if self.profile and inp.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.pg, async_op=False)
+            e1.record()
+            self.events.append((e0, e1, out.numel() * out.element_size()))
+            return _Done()
         return dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.pg, async_op=True)
+
+    def profile_summary(self) -> dict:
+        """{calls, ms, bytes} of the all-gathers recorded in measurement mode (synchronises the device)."""
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.events)
+        out = dict(calls=len(self.events), ms=ms, gathered_bytes=sum(n for _, _, n in self.events))
+        self.events = []
+        return out
 
 
 class ThreadWorld:
