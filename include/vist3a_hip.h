@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 15) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 16) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -284,6 +284,30 @@ int v3a_conf_quantile_compact(const float* conf, float q, const float* pts, cons
 int v3a_gaussian_adapter(const float* pts, const float* feats, int ldf, long U, int sh_degree, float opacity_exponent,
                          const float* sh_mask, float* means, float* cov, float* sh, float* opac, float* scales, float* rot,
                          void* stream);
+
+/* One denoise step's glue between two DiT forwards, as ONE launch: unpatchify of the DiT output tokens, classifier-free guidance,
+ * flow-prediction -> x0, UniPC corrector + predictor, and the patchified bf16 input tokens of the next forward.  Replaces the ~25
+ * tensor ops of diffusers 0.33.1 `WanPipeline.__call__` (loop body) + `UniPCMultistepScheduler.step` that the reference runs per step
+ * (/root/reference/inference_t23d.py:94-103; restated as tensor ops in vist3a_amd/wan/{pipeline,scheduler}.py) with the same
+ * rounding points, bit for bit.  The scalar coefficients are the host-side fp32 values `UniPCMultistepScheduler.plan_step` returns. */
+typedef struct {
+  const void* dit_out;        /* [batch * N][4 C] bf16: DiT output tokens, column (ph * 2 + pw) * C + c; item 0 = conditional, 1 = unconditional */
+  void* tok;                  /* [batch * N][4 C] bf16: next forward's input tokens, column c * 4 + ph * 2 + pw (may be NULL) */
+  const float* sample;        /* [C][T][H][W] fp32 current latents */
+  const float* last_sample;   /* corrected sample of the previous step (corr_order > 0) */
+  const float* m_prev1;       /* x0 prediction of the previous step (model_outputs[-1]) */
+  const float* m_prev2;       /* ... of the step before (order-2 corrector) */
+  float* m_out;               /* this step's x0 prediction */
+  float* sample_corrected;    /* corrector output (= sample when corr_order == 0): next step's last_sample */
+  float* prev;                /* predictor output: next step's latents */
+  int C, T, H, W, batch, guided;
+  float guidance, sigma;
+  int corr_order;             /* 0 = no corrector (first step), 1, 2 */
+  float cc1, cc2, cc3, c_rho_last, c_rho0, c_inv_rk;
+  int pred_order;             /* 1, 2 */
+  float pc1, pc2, pc3, p_rho0, p_inv_rk;
+} v3a_unipc_step_args;
+int v3a_unipc_cfg_step(const v3a_unipc_step_args* args, void* stream);
 /* fp32 camera-head primitives (vggt/heads/camera_head.py:87-170): y[M<=32][N] = act(x.W^T + b) * gamma + residual */
 int v3a_linear_f32(const float* x, const float* w, const float* bias, float* y, const float* residual, const float* gamma,
                    int M, int N, int K, int ldx, int ldy, int ldr, int act, void* stream);

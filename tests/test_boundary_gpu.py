@@ -206,3 +206,73 @@ def test_rccl_scene_parallel_denoise_matches_single_gpu(hip_lib, tmp_path, world
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("[")][-1]
     assert json.loads(line) == [True] * world
+
+
+def _tiny_dit():
+    from oracle import wan_dit as O
+    from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
+    kw = dict(num_attention_heads=2, attention_head_dim=128, ffn_dim=512, num_layers=2, text_dim=128, freq_dim=64)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(O.WanDiTConfig(**kw), seed=3).items()}
+    return WanDiT(WanDiTConfig(**kw), sd, device="cuda")
+
+
+@pytest.mark.parametrize("steps,guidance,shape", [(7, 7.5, (1, 16, 2, 16, 16)), (3, 1.0, (1, 16, 1, 8, 12)), (50, 6.0, (1, 16, 1, 8, 8))])
+def test_fused_denoise_loop_is_bit_identical_to_tensor_ops(hip_lib, steps, guidance, shape):
+    """One launch per step (csrc/denoise_step.hip: unpatchify + classifier-free guidance + UniPC corrector / predictor + next-step
+    patchify, time conditioning of the schedule computed up front) against the loop of PyTorch tensor ops that restates diffusers'
+    WanPipeline / UniPCMultistepScheduler.step op by op: the latents after the whole schedule must agree bit for bit (first step without
+    corrector, order-1 and order-2 corrector, order-2 predictor, the final order-1 step, guided and unguided)."""
+    from vist3a_amd.wan.pipeline import WanT2VPipeline
+    from vist3a_amd.wan.scheduler import UniPCMultistepScheduler
+    model = _tiny_dit()
+    g = torch.Generator().manual_seed(steps)
+    pe = (torch.randn(1, 24, 128, generator=g) * 0.5)
+    ne = (torch.randn(1, 24, 128, generator=g) * 0.5)
+    lat0 = torch.randn(shape, generator=g)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, height=shape[3] * 8, width=shape[4] * 8, num_frames=(shape[2] - 1) * 4 + 1,
+              num_inference_steps=steps, guidance_scale=guidance)
+    outs = {}
+    for fused in (False, True):
+        pipe = WanT2VPipeline(model, UniPCMultistepScheduler(flow_shift=5.0))
+        pipe.fused = fused
+        outs[fused] = pipe(latents=lat0.clone(), **kw)["frames"].clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[True]).all()
+    d = (outs[True] - outs[False]).abs().max().item()
+    assert torch.equal(outs[True], outs[False]), f"fused loop differs from the tensor-op loop: max abs {d}"
+
+
+def test_fused_step_kernel_matches_tensor_ops_for_every_order(hip_lib):
+    """The step kernel alone, on random fp32 / bf16 inputs, for every (corrector order, predictor order) pair the scheduler can ask for:
+    the PyTorch expression sequence of scheduler.py::_correct / _predict, evaluated on the GPU, bit for bit."""
+    from vist3a_amd import ops
+    from vist3a_amd.wan.scheduler import UniPCMultistepScheduler
+    g = torch.Generator(device="cuda").manual_seed(5)
+    C, T, H, W = 16, 2, 8, 12
+    N = T * (H // 2) * (W // 2)
+    sch = UniPCMultistepScheduler(flow_shift=5.0)
+    sch.set_timesteps(9)
+    cur = torch.randn(1, C, T, H, W, device="cuda", generator=g)
+    last = torch.empty_like(cur)
+    m_a, m_b = torch.empty_like(cur), torch.empty_like(cur)
+    tok = torch.empty(2 * N, 4 * C, device="cuda", dtype=torch.bfloat16)
+    ref = UniPCMultistepScheduler(flow_shift=5.0)
+    ref.set_timesteps(9, device="cuda")
+    x_ref = cur.clone()
+    m1 = m2 = None
+    seen = set()
+    for i, t in enumerate(ref.timesteps):
+        out_tok = torch.randn(2 * N, 4 * C, device="cuda", generator=g).to(torch.bfloat16)
+        # tensor-op reference: unpatchify, guidance in bf16, scheduler.step
+        o = out_tok.view(2, T, H // 2, W // 2, 1, 2, 2, C).permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(2, C, T, H, W)
+        noise = o[1:2] + 7.5 * (o[0:1] - o[1:2])
+        x_ref = ref.step(noise, t, x_ref)[0]
+        c = sch.plan_step()
+        seen.add((c["corr_order"], c["pred_order"]))
+        m_out = m_b if m1 is m_a else m_a
+        ops.unipc_cfg_step(out_tok, tok, cur, last if c["corr_order"] else None, m1, m2, m_out, last, cur, batch=2, guidance=7.5, coeffs=c)
+        m2, m1 = m1, m_out
+        assert torch.equal(cur, x_ref), (i, c["corr_order"], c["pred_order"], (cur - x_ref).abs().max().item())
+        want_tok = x_ref.to(torch.bfloat16).expand(2, -1, -1, -1, -1).view(2, C, T, 1, H // 2, 2, W // 2, 2).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(2 * N, 4 * C)
+        assert torch.equal(tok, want_tok)
+    assert seen == {(0, 1), (1, 2), (2, 2), (2, 1)}, seen

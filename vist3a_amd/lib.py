@@ -72,6 +72,18 @@ class GsProjectArgs(C.Structure):
     ]
 
 
+class UniPCStepArgs(C.Structure):
+    _fields_ = [
+        ("dit_out", C.c_void_p), ("tok", C.c_void_p), ("sample", C.c_void_p), ("last_sample", C.c_void_p), ("m_prev1", C.c_void_p),
+        ("m_prev2", C.c_void_p), ("m_out", C.c_void_p), ("sample_corrected", C.c_void_p), ("prev", C.c_void_p),
+        ("C", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("batch", C.c_int), ("guided", C.c_int),
+        ("guidance", C.c_float), ("sigma", C.c_float),
+        ("corr_order", C.c_int), ("cc1", C.c_float), ("cc2", C.c_float), ("cc3", C.c_float), ("c_rho_last", C.c_float), ("c_rho0", C.c_float),
+        ("c_inv_rk", C.c_float),
+        ("pred_order", C.c_int), ("pc1", C.c_float), ("pc2", C.c_float), ("pc3", C.c_float), ("p_rho0", C.c_float), ("p_inv_rk", C.c_float),
+    ]
+
+
 class GsRasterizeArgs(C.Structure):
     _fields_ = [
         ("radii", C.c_void_p), ("means2d", C.c_void_p), ("depths", C.c_void_p), ("conics", C.c_void_p), ("colors", C.c_void_p),
@@ -165,6 +177,7 @@ SYMBOLS = {
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "v3a_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "v3a_attention_set_kernel": (C.c_int, [C.c_int]),
+    "v3a_unipc_cfg_step": (C.c_int, [C.POINTER(UniPCStepArgs), C.c_void_p]),
     "v3a_attention_fwd_fp8": (C.c_int, [C.POINTER(AttnFp8Args), C.c_void_p]),
     "v3a_gemm_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "v3a_gemm_pick_tile_act": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -199,7 +212,7 @@ SYMBOLS = {
 }
 
 _lib = None
-EXPECTED_ABI = 15   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
+EXPECTED_ABI = 16   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
 
 
 class HipLibraryError(RuntimeError):

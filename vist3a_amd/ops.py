@@ -618,6 +618,30 @@ def attention_small_f32(qkv: torch.Tensor, H: int) -> torch.Tensor:
     return out
 
 
+def unipc_cfg_step(dit_out: torch.Tensor, tok: Optional[torch.Tensor], sample: torch.Tensor, last_sample: Optional[torch.Tensor],
+                   m_prev1: Optional[torch.Tensor], m_prev2: Optional[torch.Tensor], m_out: torch.Tensor, sample_corrected: torch.Tensor,
+                   prev: torch.Tensor, *, batch: int, guidance: Optional[float], coeffs: dict) -> None:
+    """One launch for unpatchify + CFG + UniPC step + next-step patchify (csrc/denoise_step.hip).  `coeffs` = the host scalars of
+    `UniPCMultistepScheduler.plan_step()`; latents [1, C, T, H, W] fp32, token buffers as WanDiT keeps them."""
+    if sample.dtype != f32 or not sample.is_contiguous() or sample.dim() != 5 or sample.shape[0] != 1:
+        raise ValueError("sample must be contiguous f32 [1, C, T, H, W]")
+    _, Cc, T, H, W = sample.shape
+    N = T * (H // 2) * (W // 2)
+    for name, t_ in (("m_out", m_out), ("sample_corrected", sample_corrected), ("prev", prev), ("last_sample", last_sample),
+                     ("m_prev1", m_prev1), ("m_prev2", m_prev2)):
+        if t_ is not None and (t_.dtype != f32 or not t_.is_contiguous() or t_.numel() != sample.numel()):
+            raise ValueError(f"{name} must be contiguous f32 with the latents' shape")
+    for name, t_ in (("dit_out", dit_out), ("tok", tok)):
+        if t_ is not None and (t_.dtype != bf16 or not t_.is_contiguous() or t_.shape != (batch * N, 4 * Cc)):
+            raise ValueError(f"{name} must be contiguous bf16 [{batch * N}, {4 * Cc}]")
+    c = coeffs
+    a = L.UniPCStepArgs(_ptr(dit_out), _ptr(tok), _ptr(sample), _ptr(last_sample), _ptr(m_prev1), _ptr(m_prev2), _ptr(m_out),
+                        _ptr(sample_corrected), _ptr(prev), Cc, T, H, W, batch, int(guidance is not None), float(guidance or 0.0), c["sigma"],
+                        c["corr_order"], c["cc1"], c["cc2"], c["cc3"], c["c_rho_last"], c["c_rho0"], c["c_inv_rk"],
+                        c["pred_order"], c["pc1"], c["pc2"], c["pc3"], c["p_rho0"], c["p_inv_rk"])
+    L.check(L.load().v3a_unipc_cfg_step(C.byref(a), _stream()), "v3a_unipc_cfg_step")
+
+
 # ------------------------------------------------------------------------------------------------ 3DGS rasteriser
 def gs_project(means: torch.Tensor, covars: torch.Tensor, sh: torch.Tensor, viewmat: torch.Tensor, campos: torch.Tensor,
                K: torch.Tensor, width: int, height: int, *, sh_degree: int = 4, sh_layout: int = 1, near_plane: float = 1e-10,

@@ -267,12 +267,16 @@ class WanDiT:
 
     # ---------------------------------------------------------------- forward
     @torch.no_grad()
-    def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
-                return_dict: bool = False, num_layers: Optional[int] = None, sp=None):
+    def forward(self, hidden_states: Optional[torch.Tensor], timestep, encoder_hidden_states: torch.Tensor,
+                return_dict: bool = False, num_layers: Optional[int] = None, sp=None, tokens_in: bool = False, tokens_out: bool = False,
+                latent_shape: Optional[tuple] = None, time_table: Optional[tuple] = None):
         """`sp` (wan/seqpar.py group) shards the latent tokens over sp.world ranks: every rank passes the SAME full
-        `hidden_states` and gets the full prediction back; only N/P token rows are computed locally."""
+        `hidden_states` and gets the full prediction back; only N/P token rows are computed locally.
+        Fused denoise loop (wan/pipeline.py): `tokens_in` = the patchified input already sits in `token_buffers()[0]` (written by
+        ops.unipc_cfg_step; `hidden_states` may be None, `latent_shape` gives [B, C, T, H, W]); `tokens_out` = return the raw output
+        tokens (`token_buffers()[1]`) instead of the un-patchified tensor; `time_table` = this step's (temb, mod) from `time_tables()`."""
         cfg = self.cfg
-        B, C, Fr, Hh, Ww = hidden_states.shape
+        B, C, Fr, Hh, Ww = hidden_states.shape if hidden_states is not None else latent_shape
         pt, ph, pw = cfg.patch_size
         ppf, pph, ppw = Fr // pt, Hh // ph, Ww // pw
         N, d, H, hd = ppf * pph * ppw, cfg.dim, cfg.num_attention_heads, cfg.attention_head_dim
@@ -291,20 +295,21 @@ class WanDiT:
         ks, vts, Lt, Lp, kbias, Lk, merged = self._context(encoder_hidden_states)
 
         # patchify: Conv3d(k=s=(1,2,2)) == GEMM over (c,pt,ph,pw)-major patches
-        x5 = hidden_states.to(bf16).view(B, C, ppf, pt, pph, ph, ppw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
-        if P == 1:
-            ws.tok.view(B, ppf, pph, ppw, C, pt, ph, pw).copy_(x5)
-        else:
-            ws.tok.view(B, Nl, -1).copy_(x5.reshape(B, N, -1)[:, rk * Nl:(rk + 1) * Nl])
+        if not tokens_in:
+            x5 = hidden_states.to(bf16).view(B, C, ppf, pt, pph, ph, ppw, pw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+            if P == 1:
+                ws.tok.view(B, ppf, pph, ppw, C, pt, ph, pw).copy_(x5)
+            else:
+                ws.tok.view(B, Nl, -1).copy_(x5.reshape(B, N, -1)[:, rk * Nl:(rk + 1) * Nl])
+        elif P != 1:
+            raise ValueError("tokens_in is the single-GPU fused loop's path")
         x = ops.gemm(ws.tok, self.patch_w, self.patch_b, out=ws.x)
 
         # time conditioning (M = B rows: latency-only work)
-        te = timestep.to(device=self.device, dtype=f32)[:, None] * self._tfreq[None]
-        te = torch.cat([te.cos(), te.sin()], -1).to(bf16)
-        t1 = ops.gemm(te, self.te1_w, self.te1_b, act=L.ACT_SILU)
-        temb = ops.gemm(t1, self.te2_w, self.te2_b)
-        tproj = ops.gemm(torch.nn.functional.silu(temb.float()).to(bf16), self.tp_w, self.tp_b)  # [B,6d]
-        mod = (self.sst[:, None] + tproj.float().view(1, B, 6, d)).contiguous()  # [L,B,6,d] f32
+        if time_table is not None:
+            temb, mod = time_table
+        else:
+            temb, mod = self._time_conditioning(timestep.to(device=self.device, dtype=f32), B)
 
         nl = cfg.num_layers if num_layers is None else num_layers
         Ml = B * Nl
@@ -444,6 +449,10 @@ class WanDiT:
         om = (self.out_sst[None] + temb.float()[:, None]).contiguous()  # [B,2,d]
         ops.layernorm(x, out=ws.n, scale=om[:, 1], shift=om[:, 0], rows_per_batch=Nl, eps=cfg.eps)
         ops.gemm(ws.n, self.po_w, self.po_b, out=ws.out)
+        if tokens_out:
+            if P != 1:
+                raise ValueError("tokens_out is the single-GPU fused loop's path")
+            return ws.out if return_dict else (ws.out,)
         if P == 1:
             tokens = ws.out
         else:
@@ -454,6 +463,44 @@ class WanDiT:
         return o if return_dict else (o,)
 
     __call__ = forward
+
+    def _time_conditioning(self, t: torch.Tensor, B: int):
+        """timesteps [R] f32 (R = B per-item values, or the distinct steps of a whole schedule) -> (temb [R, d] bf16, mod): with R == B the
+        per-block modulation table [L, B, 6, d] f32 of ONE step; rows are independent, so a schedule's R steps can go through the three
+        skinny GEMMs as one batch (`time_tables`)."""
+        d = self.cfg.dim
+        te = t[:, None] * self._tfreq[None]
+        te = torch.cat([te.cos(), te.sin()], -1).to(bf16)
+        t1 = ops.gemm(te, self.te1_w, self.te1_b, act=L.ACT_SILU)
+        temb = ops.gemm(t1, self.te2_w, self.te2_b)
+        tproj = ops.gemm(torch.nn.functional.silu(temb.float()).to(bf16), self.tp_w, self.tp_b)  # [R,6d]
+        mod = (self.sst[:, None] + tproj.float().view(1, t.shape[0], 6, d)).contiguous()  # [L,R,6,d] f32
+        return temb, mod
+
+    @torch.no_grad()
+    def time_tables(self, timesteps: torch.Tensor, B: int):
+        """The time conditioning of a whole schedule at once: it depends on the timestep only, so the fused denoise loop computes it
+        for all S steps in ONE pass of the embedder (three skinny GEMMs over S rows) instead of S passes over B identical rows.
+        -> list of S (temb [B, d], mod [L, B, 6, d]) pairs, bit-identical per step to `_time_conditioning(t.expand(B))`."""
+        t = timesteps.to(device=self.device, dtype=f32)
+        out = []
+        for s0 in range(0, t.shape[0], 64):   # (<= 128 rows per skinny GEMM)
+            temb, mod = self._time_conditioning(t[s0:s0 + 64], B)
+            for i in range(temb.shape[0]):
+                out.append((temb[i:i + 1].expand(B, -1).contiguous(), mod[:, i:i + 1].expand(-1, B, -1, -1).contiguous()))
+        return out
+
+    def token_buffers(self, B: int, latent_shape: tuple):
+        """(input tokens [B N, 64] bf16, output tokens [B N, 64] bf16) of the workspace `forward` uses for this shape on this thread."""
+        cfg = self.cfg
+        _, C, Fr, Hh, Ww = latent_shape
+        pt, ph, pw = cfg.patch_size
+        N = (Fr // pt) * (Hh // ph) * (Ww // pw)
+        wkey = (B, N, 1, 0, threading.get_ident())
+        ws = self._ws.get(wkey)
+        if ws is None:
+            ws = self._ws[wkey] = _Workspace(B, N, N, 1, cfg, self.device)
+        return ws.tok, ws.out
 
 
 class GraphedWanDiT:

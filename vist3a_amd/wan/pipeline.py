@@ -39,6 +39,33 @@ class WanT2VPipeline:
         self.text_encoder = text_encoder
         self.device = torch.device(device)
 
+    fused = True   # one launch per step for guidance + UniPC + (un)patchify (csrc/denoise_step.hip); False = the tensor-op loop below
+
+    def _fused_loop(self, latents: torch.Tensor, text: torch.Tensor, nb: int, shape: tuple, guidance: Optional[float]) -> torch.Tensor:
+        """The denoise loop with everything between two DiT forwards in ONE kernel (ops.unipc_cfg_step) and the time conditioning of
+        the whole schedule computed up front (WanDiT.time_tables): per step = one DiT forward + one launch.  Bit-identical to the
+        tensor-op loop (tests/test_boundary_gpu.py::test_fused_denoise_loop_is_bit_identical_to_tensor_ops)."""
+        from .. import ops
+        dit, sch = self.transformer, self.scheduler
+        bf16 = torch.bfloat16
+        tok, out_tok = dit.token_buffers(nb, shape)
+        tables = dit.time_tables(sch.timesteps, nb)
+        cur = latents.contiguous().clone()
+        last, m_a, m_b = torch.empty_like(cur), torch.empty_like(cur), torch.empty_like(cur)
+        # first step's input tokens: the one patchify that is not produced by the step kernel
+        B, C, T, H, W = (nb,) + tuple(shape[1:])
+        x5 = cur.to(bf16).expand(nb, -1, -1, -1, -1).view(nb, C, T, 1, H // 2, 2, W // 2, 2).permute(0, 2, 4, 6, 1, 3, 5, 7)
+        tok.view(nb, T, H // 2, W // 2, C, 1, 2, 2).copy_(x5)
+        m1 = m2 = None
+        for i in range(len(sch.timesteps)):
+            dit.forward(None, None, text, tokens_in=True, tokens_out=True, latent_shape=(nb,) + tuple(shape[1:]), time_table=tables[i])
+            c = sch.plan_step()
+            m_out = m_b if m1 is m_a else m_a         # overwrites the older of the two x0 predictions (read by its own thread first)
+            ops.unipc_cfg_step(out_tok, tok, cur, last if c["corr_order"] else None, m1, m2, m_out, last, cur, batch=nb, guidance=guidance,
+                               coeffs=c)
+            m2, m1 = m1, m_out
+        return cur
+
     def encode_prompt(self, prompt: Union[str, List[str]], max_sequence_length: int = 512) -> torch.Tensor:
         if self.text_encoder is None:
             raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds "
@@ -83,6 +110,14 @@ class WanT2VPipeline:
             text = prompt_embeds.to(self.device).contiguous()
         nb = text.shape[0]
         pair = torch.empty((2,) + shape, device=self.device, dtype=torch.bfloat16) if cfgp is not None else None
+        if self.fused and self.plan is None and callback is None and hasattr(self.transformer, "token_buffers") \
+                and tuple(getattr(self.transformer.cfg, "patch_size", ())) == (1, 2, 2) and hasattr(self.scheduler, "plan_step"):
+            latents = self._fused_loop(latents, text, nb, shape, guidance_scale if do_cfg else None)
+            if output_type == "latent":
+                return {"frames": latents}
+            if self.vae is None:
+                raise RuntimeError("output_type != 'latent' needs a VAE")
+            return {"frames": self.vae.decode(denormalize_latents(latents), return_dict=False)[0]}
         for i, t in enumerate(self.scheduler.timesteps):
             x_in = latents.to(torch.bfloat16).expand(nb, -1, -1, -1, -1)
             noise = self.transformer(x_in, t.expand(nb), text, return_dict=False, sp=sp)[0]

@@ -136,6 +136,49 @@ class UniPCMultistepScheduler:
         x_t = x_t - (alpha_t * B_h).item() * (corr + rhos[-1].item() * (this_m - m0))
         return x_t.to(last_sample.dtype)
 
+    def plan_step(self) -> dict:
+        """Host half of `step` for the fused device kernel (ops.unipc_cfg_step / csrc/denoise_step.hip): the same control flow and the
+        same fp32 coefficient arithmetic as `step` / `_correct` / `_predict`, returned as plain floats; advances the step counters but
+        touches no tensor (the kernel keeps sample, last_sample and the two x0 predictions on the device).  Do not mix with `step`
+        inside one schedule."""
+        if self.sigmas is None:
+            raise ValueError("call set_timesteps first")
+        if self._step_index is None:
+            self._step_index = 0
+            self._planned_last = False
+        si = self._step_index
+        c = dict(sigma=float(self.sigmas[si]), corr_order=0, cc1=0.0, cc2=0.0, cc3=0.0, c_rho_last=0.0, c_rho0=0.0, c_inv_rk=0.0,
+                 pred_order=1, pc1=0.0, pc2=0.0, pc3=0.0, p_rho0=0.5, p_inv_rk=0.0)
+        inv32 = lambda r: float(np.float32(1.0) / np.float32(r))   # ATen's CUDA `tensor / scalar` = tensor * (1 / scalar) in fp32
+        if si > 0 and (si - 1) not in self.disable_corrector and self._planned_last:
+            order = self.this_order
+            s_t, s_0 = self.sigmas[si], self.sigmas[si - 1]
+            rks, R, b, h_phi_1, B_h = self._coeffs(order, s_t, s_0, [self.sigmas[si - (i + 1)] for i in range(1, order)])
+            alpha_t = 1 - s_t
+            rhos = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(R, b)
+            c.update(corr_order=order, cc1=(s_t / s_0).item(), cc2=(alpha_t * h_phi_1).item(), cc3=(alpha_t * B_h).item(),
+                     c_rho_last=rhos[-1].item())
+            if order == 2:
+                c.update(c_rho0=rhos[0].item(), c_inv_rk=inv32(rks[0].item()))
+            elif order > 2:
+                raise NotImplementedError("fused step: solver_order <= 2")
+        this_order = min(self.solver_order, len(self.timesteps) - si) if self.lower_order_final else self.solver_order
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        order = self.this_order
+        s_t, s_0 = self.sigmas[si + 1], self.sigmas[si]
+        rks, R, b, h_phi_1, B_h = self._coeffs(order, s_t, s_0, [self.sigmas[si - i] for i in range(1, order)])
+        alpha_t = 1 - s_t
+        c.update(pred_order=order, pc1=(s_t / s_0).item(), pc2=(alpha_t * h_phi_1).item())
+        if order == 2:
+            c.update(pc3=(alpha_t * B_h).item(), p_rho0=0.5, p_inv_rk=inv32(rks[0].item()))
+        elif order > 2:
+            raise NotImplementedError("fused step: solver_order <= 2")
+        if self.lower_order_nums < self.solver_order:
+            self.lower_order_nums += 1
+        self._step_index += 1
+        self._planned_last = True
+        return c
+
     def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, return_dict: bool = False):
         if self.sigmas is None:
             raise ValueError("call set_timesteps first")
@@ -143,9 +186,9 @@ class UniPCMultistepScheduler:
             self._step_index = 0
         si = self._step_index
         use_corrector = si > 0 and (si - 1) not in self.disable_corrector and self.last_sample is not None
-        # flow prediction -> x0.  sigma stays a 0-d float32 TENSOR here on purpose: torch then multiplies in the
-        # model-output dtype (sigma rounded to bf16 first), exactly what the reference's scheduler does; a Python
-        # float would keep sigma in fp32 and change the last bit of sigma*v.
+        # flow prediction -> x0.  sigma is a 0-d float32 host tensor: ATen multiplies the bf16 model output by the fp32 scalar in fp32 and
+        # rounds the product to bf16 (measured on MI355X, round 3: `sig * v == bf16(float(v) * sig)` bit for bit; the scalar is NOT
+        # rounded to bf16 first) - the same as the reference's scheduler, and what csrc/denoise_step.hip reproduces.
         m = sample - self.sigmas[si] * model_output
         if use_corrector:
             sample = self._correct(m, self.last_sample, self.this_order)
