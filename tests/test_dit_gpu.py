@@ -36,7 +36,7 @@ def tiny(hip_lib):
 
 
 @pytest.mark.parametrize("shape,L", [((2, 16, 2, 16, 16), 64), ((1, 16, 3, 8, 16), 40), ((2, 16, 1, 32, 32), 512)])
-def test_forward_matches_oracle(tiny, shape, L):
+def test_forward_matches_oracle(tiny, parity, shape, L):
     ocfg, sd, model = tiny
     g = torch.Generator().manual_seed(5)
     lat = torch.randn(shape, generator=g)
@@ -51,7 +51,12 @@ def test_forward_matches_oracle(tiny, shape, L):
     assert out.shape == lat.shape and out.dtype == torch.bfloat16
     assert torch.isfinite(out.float()).all()
     r1, r2 = _rel(out, ref_emu), _rel(out, ref_f32)
-    print(f"rel vs emu-oracle {r1:.3e}  vs fp32-oracle {r2:.3e}")
+    # the reference loads the DiT in fp16 (inference_t23d.py:73) and diffusers' RMSNorm casts q / k to that dtype before RoPE: one more
+    # rounding point (fp16, 11 bits) in front of the bf16 one the HIP kernel has - its effect on the output, measured, not asserted on
+    ref_h16 = O.dit_forward(sd, ocfg, lat_b.float(), t, text.to(torch.bfloat16).float(), emulate_bf16=True, fp16_norm=True)
+    parity("dit_two_blocks_tiny", shape=str(shape), rel_vs_emu_oracle=r1, rel_vs_fp32_oracle=r2, rel_vs_fp16_rmsnorm_oracle=_rel(out, ref_h16),
+           fp16_rmsnorm_oracle_vs_emu_oracle=_rel(ref_h16, ref_emu))
+    print(f"rel vs emu-oracle {r1:.3e}  vs fp32-oracle {r2:.3e}  vs oracle with fp16 q/k RMSNorm output {_rel(out, ref_h16):.3e}")
     assert r1 < 3.4e-3, r1      # measured 1.4e-3 .. 1.7e-3 on MI355X
     assert r2 < 9.4e-3, r2      # measured 4.7e-3
 
