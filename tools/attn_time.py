@@ -1,11 +1,11 @@
 """Time + check the DiT self-attention launch (B=2, H=12, N=4096, D=128): kernel 1 (128-query workgroups, three per CU) against kernel 2
 (256-query workgroups, one wave per SIMD, 64 queries per wave) in ONE process; outputs must be bit-identical."""
-import sys, json
+import sys, json, os
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from vist3a_amd import lib, ops
-shapes = [(2, 12, 4096), (2, 16, 4096), (2, 12, 6144)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
+shapes = [(2, 12, 4096)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
 D = 128
 L = lib.load()
 for B, H, N in shapes:
@@ -18,7 +18,7 @@ for B, H, N in shapes:
     for b in range(B):
         vt[:, b * N:(b + 1) * N] = v[b * N:(b + 1) * N].t()
     outs = {}
-    for which in (1, 2, 3):
+    for which in ((1, 2, 3) if os.environ.get("V3A_LIB") else (1,)):   # 2 / 3 exist only in -DV3A_ATTN_EXPERIMENTAL builds (tools/abl_build.sh)
         L.v3a_attention_set_kernel(which)
         o = torch.empty(B * N, d, device="cuda", dtype=torch.bfloat16)
         run = lambda: ops.attention(q, k, vt, o, B=B, H=H, Nq=N, Nk=N, D=D, q_batch_stride=N * d, k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=N * d)
@@ -38,5 +38,6 @@ for B, H, N in shapes:
         outs[which] = o.clone()
         print(json.dumps(dict(B=B, H=H, N=N, kernel=which, us=round(us, 1), rounds_us=times, tflops=round(4 * B * H * N * N * D / us / 1e6), rel=rel)), flush=True)
     L.v3a_attention_set_kernel(0)
-    print(json.dumps(dict(B=B, H=H, N=N, bit_identical_2=bool(torch.equal(outs[1], outs[2])), bit_identical_3=bool(torch.equal(outs[1], outs[3])),
-                          max_abs_diff_3=(outs[1].float() - outs[3].float()).abs().max().item())), flush=True)
+    if 2 in outs:
+        print(json.dumps(dict(B=B, H=H, N=N, bit_identical_2=bool(torch.equal(outs[1], outs[2])), bit_identical_3=bool(torch.equal(outs[1], outs[3])),
+                              max_abs_diff_3=(outs[1].float() - outs[3].float()).abs().max().item())), flush=True)

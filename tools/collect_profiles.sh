@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=$R/gpurun_out
 mkdir -p $O
-python -m pytest tests -q -m gpu -s > $O/prof_gputest_stdout.log 2>&1
+python -m pytest tests -q -m gpu -rP > $O/prof_gputest_stdout.log 2>&1
 tail -3 $O/prof_gputest_stdout.log
 cp $O/parity.json $O/prof_parity.json
 python bench.py 2>/dev/null | tail -1 > $O/prof_bench_default_run.json
@@ -23,5 +23,5 @@ python tools/sp_rank_time.py 2>/dev/null | tail -8 > $O/prof_sp_rank_time_1_3b.j
 python tools/sp_rank_time.py 14b 2>/dev/null | tail -8 > $O/prof_sp_rank_time_14b.jsonl
 python tools/gemm_sweep.py 6,8,7 0,1,2,3,4,8 2>/dev/null | grep "^{" > $O/prof_gemm_sweep.jsonl
 python tools/gemm_fp8_time.py 2>/dev/null | grep "^{" > $O/prof_gemm_fp8.jsonl
-python tools/attn_time.py 2>/dev/null | tail -1 > $O/prof_attn_time.json
+python tools/attn_time.py 2x12x4096 2x12x6144 2>/dev/null | grep '^{' > $O/prof_attn_time.jsonl
 ls -la $O | head -40
