@@ -18,7 +18,7 @@ for B, H, N in shapes:
     for b in range(B):
         vt[:, b * N:(b + 1) * N] = v[b * N:(b + 1) * N].t()
     outs = {}
-    for which in ((1, 2, 3) if os.environ.get("V3A_LIB") else (1,)):   # 2 / 3 exist only in -DV3A_ATTN_EXPERIMENTAL builds (tools/abl_build.sh)
+    for which in ((1, 2, 3) if os.environ.get("V3A_ATTN_STUDY") else (1,)):   # 2 / 3 exist only in -DV3A_ATTN_EXPERIMENTAL builds (tools/abl_build.sh)
         L.v3a_attention_set_kernel(which)
         o = torch.empty(B * N, d, device="cuda", dtype=torch.bfloat16)
         run = lambda: ops.attention(q, k, vt, o, B=B, H=H, Nq=N, Nk=N, D=D, q_batch_stride=N * d, k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=N * d)

@@ -30,6 +30,9 @@
 #include "common.h"
 #include "../../include/vist3a_hip.h"
 
+#ifndef V3A_ATTN_PF
+#define V3A_ATTN_PF 2
+#endif
 #ifndef V3A_PW_ABL
 #define V3A_PW_ABL 0     // experiment builds only (tools/abl_build.sh)
 #endif
@@ -60,7 +63,9 @@ struct AttnP {
 //   V1 = true : K double-, V^T SINGLE-buffered (48 KB) and fetched under S and the softmax of its own tile, THREE workgroups per CU -
 //               the DiT's 98304 query rows are exactly 12 waves of 32 per CU (3 x 4 waves is one full round where 2 x 4 leaves a
 //               half-empty second one); one extra barrier per tile orders the V^T landing before the PV MFMAs.
-template <int D, int NW, bool RELB, bool KBIAS, bool V1>
+// RAG = false ("plain"): the caller guarantees Nk % 64 == 0, kv_period == 0 and kv_seg == 0 - the ragged-tile DMA path, the tail mask, the
+// filler-row mask and the segment arithmetic are compiled out (as never-taken branches they cost the DiT self-attention 2 %: 100 -> 73 SGPRs).
+template <int D, int NW, bool RELB, bool KBIAS, bool V1, bool RAG = true>
 __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const AttnP p) {
   constexpr int KSTRIDE = V1 ? 64 * D * 2 : 64 * D * 2 + D * 128;   // distance between the two K buffers
   constexpr int KV = 64;                 // keys per tile
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
+  constexpr int PF = V3A_ATTN_PF;   // LDS fragment reads in flight ahead of the MFMA that consumes them
 
   // block -> (batch, head, query block); consecutive blocks of one (batch, head) share K/V in L2:
   // hardware places block b on XCD b%8, so make the q-block index vary slowest across XCD lanes.
@@ -107,42 +113,52 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
   }
 
   // ---- DMA sources ----
-  const char* kp[KINS];
-  const char* vp[VINS];
-  int krow[KINS];
+  // A DMA address = wave-uniform 64-bit base (SGPRs: batch / head slab + tile + piece) + ONE per-lane 32-bit byte offset (row inside the
+  // piece, swizzled 16-byte chunk): two v_lshl_add_u64 per piece and two VGPRs per operand for the whole loop.  (Round 2 kept KINS + VINS
+  // per-lane 64-bit pointers and rebuilt row / clamp / row x ldk per piece: 47 VALU instructions per tile incl. eight quarter-rate
+  // v_mul_lo_u32, and every attempt to hoist them spilled at the 168-register allocation.)  Only the ragged LAST tile needs per-lane row
+  // clamps: it takes the slow path below, once per workgroup, recomputed from the lane id so that it holds no register across the loop.
+  constexpr int NOFF = (KCPR == 16 && (NW * KRPI) % 16 != 0) ? 2 : 1;   // the swizzle term repeats every 16 rows (D = 128) / is piece-invariant
+  unsigned kvo[NOFF], vvo;
+  {
+    const int r0 = wave * KRPI + lane / KCPR, c = lane % KCPR;
 #pragma unroll
-  for (int j = 0; j < KINS; ++j) {
-    const int g = j * NW + wave;
-    const int r = g * KRPI + lane / KCPR;
-    const int c = lane % KCPR;
-    const int f = (KCPR == 16) ? (r & 15) : ((r >> 1) & 7);
-    krow[j] = r;
-    kp[j] = Kb + (size_t)(c ^ f) * 16;  // + row*ldk*2 added per tile (row clamp depends on tile)
-  }
-#pragma unroll
-  for (int j = 0; j < VINS; ++j) {
-    const int g = j * NW + wave;
-    const int r = g * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    vp[j] = Vb + ((size_t)r * p.ldvt + c * 8) * 2;
+    for (int o = 0; o < NOFF; ++o) {
+      const int r = o * NW * KRPI + r0;
+      const int f = (KCPR == 16) ? (r & 15) : ((r >> 1) & 7);
+      kvo[o] = (unsigned)((c ^ f) * 16) + (unsigned)r0 * (unsigned)p.ldk * 2u;
+    }
+    const int rv = wave * 8 + (lane >> 3);                                // V^T piece stride NW * 8 rows: (rv >> 1) & 7 is piece-invariant
+    vvo = ((unsigned)rv * (unsigned)p.ldvt + (unsigned)(((lane & 7) ^ ((rv >> 1) & 7)) * 8)) * 2u;
   }
   // with kv_seg (sequence-parallel: K / V^T are read straight from the all-gathered per-rank slabs, no reassembly copy) a 64-key
   // tile lies inside one segment: its wave-uniform base moves by (k_seg - kv_seg * ldk) / (vt_seg - kv_seg) per segment crossed
   auto stage_k = [&](int s, int kt) {
     char* sb = smem + s * KSTRIDE;
-    const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.k_seg - (long)p.kv_seg * p.ldk) * 2 : 0;
+    const size_t so = RAG && p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.k_seg - (long)p.kv_seg * p.ldk) * 2 : 0;
+    if (RAG && (kt + 1) * KV > p.Nk) {   // ragged last tile: rows past Nk - 1 re-read row Nk - 1 (masked to -inf below)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));   // keeps this block's address arithmetic inside the block
 #pragma unroll
-    for (int j = 0; j < KINS; ++j) {
-      int row = kt * KV + krow[j];
-      row = row < p.Nk ? row : p.Nk - 1;
-      glds16(kp[j] + (size_t)row * p.ldk * 2 + so, sb + (j * NW + wave) * 1024);
+      for (int j = 0; j < KINS; ++j) {
+        const int r = (j * NW + wave) * KRPI + ln / KCPR, c = ln % KCPR;
+        const int f = (KCPR == 16) ? (r & 15) : ((r >> 1) & 7);
+        int row = kt * KV + r;
+        row = row < p.Nk ? row : p.Nk - 1;
+        glds16(Kb + (size_t)(c ^ f) * 16 + (size_t)row * p.ldk * 2 + so, sb + (j * NW + wave) * 1024);
+      }
+    } else {
+      const size_t base = (size_t)kt * ((size_t)KV * p.ldk * 2) + so, piece = (size_t)(NW * KRPI) * p.ldk * 2;
+#pragma unroll
+      for (int j = 0; j < KINS; ++j) glds16(Kb + (base + j * piece) + (size_t)kvo[j % NOFF], sb + (j * NW + wave) * 1024);
     }
   };
   auto stage_v = [&](int s, int kt) {
     char* sv = V1 ? smem + 2 * KTILE : smem + s * KSTRIDE + KTILE;
-    const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.vt_seg - p.kv_seg) * 2 : 0;
+    const size_t so = RAG && p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.vt_seg - p.kv_seg) * 2 : 0;
+    const size_t base = (size_t)kt * KV * 2 + so, piece = (size_t)(NW * 8) * p.ldvt * 2;
 #pragma unroll
-    for (int j = 0; j < VINS; ++j) glds16(vp[j] + (size_t)kt * KV * 2 + so, sv + (j * NW + wave) * 1024);
+    for (int j = 0; j < VINS; ++j) glds16(Vb + (base + j * piece) + (size_t)vvo, sv + (j * NW + wave) * 1024);
   };
 
   // ---- fragment read offsets ----
@@ -194,13 +210,25 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
     // S^T = K . Q^T  (two 32-key sub-tiles)
     f32x16 s[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    {   // the two sub-tiles alternate (consecutive MFMAs never share an accumulator); fragment reads run PF ahead of their MFMA
+      constexpr int NF = 2 * KS;
+      auto ldk = [&](int j) { return *(const bf16x8*)(sK + (j & 1) * 32 * KROWB + kfo[j >> 1]); };
+      bf16x8 kf[NF];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(sK + t * 32 * KROWB + kfo[ks]);
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      for (int j = 0; j < PF; ++j) kf[j] = ldk(j);
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        if (j + PF < NF) kf[j + PF] = ldk(j + PF);
+        s[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j >> 1], s[j & 1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        if (j + PF < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
     }
     // lane (q = l31, hi) now holds keys kt*64 + 32*t + 16*hi + r, r = 0..15
@@ -223,7 +251,8 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
           if (key < p.Nk) s[t][r] += tb[32 * t + r] * p.inv_scale;
         }
     }
-    if (kt == nkt - 1 && (p.Nk & (KV - 1))) {
+    if (RAG && kt == nkt - 1 && (p.Nk & (KV - 1))) {
+      asm volatile("");   // a real branch: if-converted, these were 31 v_cndmask on every tile
       const int kb = kt * KV + 16 * hi;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -231,7 +260,7 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
         for (int r = 0; r < 16; ++r)
           if (kb + 32 * t + r >= p.Nk) s[t][r] = -1e30f;
     }
-    if (p.kv_period > 0) {  // padded multi-frame token layout: mask the per-frame filler rows
+    if (RAG && p.kv_period > 0) {  // padded multi-frame token layout: mask the per-frame filler rows
       const int pos = (kt * KV) % p.kv_period;
       if (pos + KV > p.kv_valid) {  // some key of this tile is filler (always true for periods < 64)
 #pragma unroll
@@ -263,30 +292,27 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
     }
     const float mc = m_run * c;
     float psum = 0.f;
-    bf16x8 pf[4];
+    // P in four 16-key chunks (= the four K-slices of the PV product), summed in key order: chunk c + 1 is exponentiated in the issue
+    // slots behind the MFMAs of chunk c (a wave issues in order: VALU work right behind an MFMA runs in its shadow)
+    u32x4 pw[4];
+    auto pquarter = [&](int c4, int q) {   // keys 2q, 2q + 1 of chunk c4: 2 x (fma, exp, add) + one pack = 7 VALU instructions
+      const int t = c4 >> 1, r0 = 8 * (c4 & 1) + 2 * q;
+      const float p0 = __builtin_amdgcn_exp2f(s[t][r0] * c - mc), p1 = __builtin_amdgcn_exp2f(s[t][r0 + 1] * c - mc);
+      psum += p0;
+      psum += p1;
+      pw[c4][q] = pack_bf16x2(p0, p1);
+    };
+    auto pchunk = [&](int c4) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float pv[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(s[t][r] * c - mc);
-        psum += pv[r];
-      }
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-        u32x4 pk;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(pv[8 * ks2 + 2 * e], pv[8 * ks2 + 2 * e + 1]);
-        pf[2 * t + ks2] = __builtin_bit_cast(bf16x8, pk);
-      }
-    }
-    l_run = l_run * alpha + psum;
+      for (int q = 0; q < 4; ++q) pquarter(c4, q);
+    };
     if (rescale) {
 #pragma unroll
       for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
     }
+    pchunk(0);
     if constexpr (V1) {
       // V^T pieces were issued before the K pieces: leave the K prefetch in flight
       if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
@@ -294,14 +320,25 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
       __builtin_amdgcn_s_barrier();  // every wave's V^T pieces have landed
     }
     // O^T += V^T . P^T
+    {
+      constexpr int NF = 4 * DT;
+      auto ldv = [&](int j) { return *(const bf16x8*)(sV + (j % DT) * 4096 + vfo[j / DT]); };
+      bf16x8 vf[NF];
 #pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) {
+      for (int j = 0; j < PF; ++j) vf[j] = ldv(j);
 #pragma unroll
-      for (int i = 0; i < DT; ++i) {
-        const bf16x8 vf = *(const bf16x8*)(sV + i * 4096 + vfo[c4]);
-        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c4], oacc[i], 0, 0, 0);
+      for (int j = 0; j < NF; ++j) {
+        if (j + PF < NF) vf[j + PF] = ldv(j + PF);
+        oacc[j % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], __builtin_bit_cast(bf16x8, pw[j / DT]), oacc[j % DT], 0, 0, 0);
+        if constexpr (DT == 4) {
+          if (j / DT + 1 < 4) pquarter(j / DT + 1, j % DT);
+        } else {   // two MFMAs per chunk (D = 64): half a chunk behind each
+          if (j / DT + 1 < 4) { pquarter(j / DT + 1, 2 * (j % DT)); pquarter(j / DT + 1, 2 * (j % DT) + 1); }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // exactly this order: read ahead, MFMA, its share of the next chunk's softmax
       }
     }
+    l_run = l_run * alpha + psum;
     // lgkmcnt(0) is essential: hipcc sinks the last PV MFMA (and the wait for its V^T fragment read) BELOW the barrier, so a
     // wave would pass it with an LDS read of the single V^T buffer still in flight while a faster wave's next-tile DMA
     // overwrites that buffer (seen as run-to-run differences in whole 32-row groups)
@@ -1058,14 +1095,14 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnP p) {
   else *(unsigned short*)o = (unsigned short)(pack_bf16x2(acc[0] * inv, 0.f) & 0xffffu);
 }
 
-template <int D, int NW, bool RELB, bool KBIAS, bool V1>
+template <int D, int NW, bool RELB, bool KBIAS, bool V1, bool RAG = true>
 int launch_attn(const AttnP& p, int B, void* stream) {
   constexpr int KT = 64 * D * 2, VT = D * 128;
   constexpr int RING = V1 ? 2 * KT + VT : 2 * (KT + VT);
   constexpr int OBYTES = NW * 32 * (D * 2 + 8);
   constexpr int LDS = RING > OBYTES ? RING : OBYTES;
   static bool attr = false;
-  auto fn = attn_fwd_kernel<D, NW, RELB, KBIAS, V1>;
+  auto fn = attn_fwd_kernel<D, NW, RELB, KBIAS, V1, RAG>;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return V3A_ERR_LAUNCH;
@@ -1160,6 +1197,7 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
     // workgroups double the count; per-wave arithmetic and key order are unchanged, so the output stays bit-identical
     const long wgs4 = (long)a->B * a->H * ((a->Nq + 127) / 128) * p.kv_split;
     if (wgs4 < 256) return launch_attn<128, 2, false, false, true>(p, a->B, stream);
+    if (a->Nk % 64 == 0 && !a->kv_period && !a->kv_seg) return launch_attn<128, 4, false, false, true, false>(p, a->B, stream);
     return launch_attn<128, 4, false, false, true>(p, a->B, stream);
   }
   return launch_attn<64, 4, false, false, false>(p, a->B, stream);  // recon (hd = 64): the 3-per-CU schedule measured no gain there
