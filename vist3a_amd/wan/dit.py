@@ -215,7 +215,7 @@ class WanDiT:
         self._tfreq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=f32) / half).to(dev)
 
     # ---------------------------------------------------------------- context (per prompt)
-    def _context(self, text: torch.Tensor):
+    def _context(self, text: torch.Tensor, lane: int = 0):
         """text [B,L,4096] -> per-block cross-attention K [B*L,d] and V^T [d,B*Lp] (+ key bias).  The results live in buffers that
         persist per (B, L) (so a captured hipGraph of `forward` stays valid across prompts) and are recomputed only when `text`
         changes.
@@ -225,7 +225,7 @@ class WanDiT:
         rows is represented by ONE key with an additive score bias log(c) — softmax over {k_1..k_n, c copies of k_pad} is
         softmax over {k_1..k_n, k_pad + log c} in exact arithmetic.  Cross-attention then runs over n+1 instead of 512 keys."""
         B, Lt, _ = text.shape
-        slot = (B, Lt, threading.get_ident())  # per thread: virtual ranks (seqpar.ThreadWorld) hold different prompts
+        slot = (B, Lt, threading.get_ident(), lane)  # per thread: virtual ranks (seqpar.ThreadWorld) hold different prompts
         # identity of the tensor OBJECT (kept alive by the cache entry, so its address cannot be recycled for another prompt's
         # embeddings while the entry is live) + its in-place version counter
         ent = self._ctx.get(slot)
@@ -269,12 +269,13 @@ class WanDiT:
     @torch.no_grad()
     def forward(self, hidden_states: Optional[torch.Tensor], timestep, encoder_hidden_states: torch.Tensor,
                 return_dict: bool = False, num_layers: Optional[int] = None, sp=None, tokens_in: bool = False, tokens_out: bool = False,
-                latent_shape: Optional[tuple] = None, time_table: Optional[tuple] = None):
+                latent_shape: Optional[tuple] = None, time_table: Optional[tuple] = None, lane: int = 0):
         """`sp` (wan/seqpar.py group) shards the latent tokens over sp.world ranks: every rank passes the SAME full
         `hidden_states` and gets the full prediction back; only N/P token rows are computed locally.
         Fused denoise loop (wan/pipeline.py): `tokens_in` = the patchified input already sits in `token_buffers()[0]` (written by
         ops.unipc_cfg_step; `hidden_states` may be None, `latent_shape` gives [B, C, T, H, W]); `tokens_out` = return the raw output
-        tokens (`token_buffers()[1]`) instead of the un-patchified tensor; `time_table` = this step's (temb, mod) from `time_tables()`."""
+        tokens (`token_buffers()[1]`) instead of the un-patchified tensor; `time_table` = this step's (temb, mod) from `time_tables()`;
+        `lane` selects an independent set of activation / prompt-context buffers (two forwards in flight on two streams)."""
         cfg = self.cfg
         B, C, Fr, Hh, Ww = hidden_states.shape if hidden_states is not None else latent_shape
         pt, ph, pw = cfg.patch_size
@@ -284,7 +285,7 @@ class WanDiT:
         if N % P or (P > 1 and (N // P) % 8):
             raise ValueError(f"{N} tokens do not split into {P} shards of a multiple of 8 rows")
         Nl = N // P  # local tokens [rk*Nl, (rk+1)*Nl) of every batch item
-        wkey = (B, N, P, rk, threading.get_ident())  # per thread: virtual ranks (seqpar.ThreadWorld) must not share buffers
+        wkey = (B, N, P, rk, threading.get_ident(), lane)  # per thread: virtual ranks (seqpar.ThreadWorld) must not share buffers
         ws = self._ws.get(wkey)
         if ws is None:
             ws = self._ws[wkey] = _Workspace(B, Nl, N, P, cfg, self.device)
@@ -292,7 +293,7 @@ class WanDiT:
         if rope is None:
             rope = self._rope[(ppf, pph, ppw)] = rope_table(cfg, ppf, pph, ppw, self.device)
         rope = rope[rk * Nl:(rk + 1) * Nl]
-        ks, vts, Lt, Lp, kbias, Lk, merged = self._context(encoder_hidden_states)
+        ks, vts, Lt, Lp, kbias, Lk, merged = self._context(encoder_hidden_states, lane)
 
         # patchify: Conv3d(k=s=(1,2,2)) == GEMM over (c,pt,ph,pw)-major patches
         if not tokens_in:
@@ -490,13 +491,13 @@ class WanDiT:
                 out.append((temb[i:i + 1].expand(B, -1).contiguous(), mod[:, i:i + 1].expand(-1, B, -1, -1).contiguous()))
         return out
 
-    def token_buffers(self, B: int, latent_shape: tuple):
+    def token_buffers(self, B: int, latent_shape: tuple, lane: int = 0):
         """(input tokens [B N, 64] bf16, output tokens [B N, 64] bf16) of the workspace `forward` uses for this shape on this thread."""
         cfg = self.cfg
         _, C, Fr, Hh, Ww = latent_shape
         pt, ph, pw = cfg.patch_size
         N = (Fr // pt) * (Hh // ph) * (Ww // pw)
-        wkey = (B, N, 1, 0, threading.get_ident())
+        wkey = (B, N, 1, 0, threading.get_ident(), lane)
         ws = self._ws.get(wkey)
         if ws is None:
             ws = self._ws[wkey] = _Workspace(B, N, N, 1, cfg, self.device)
