@@ -6,7 +6,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from vist3a_amd import lib, ops
 shapes = [(2, 12, 4096)] if len(sys.argv) < 2 else [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
-D = 128
+D = int(os.environ.get("V3A_ATTN_D", "128"))
 L = lib.load()
 for B, H, N in shapes:
     d = H * D
@@ -21,7 +21,9 @@ for B, H, N in shapes:
     for which in ((1, 2, 3) if os.environ.get("V3A_ATTN_STUDY") else (1,)):   # 2 / 3 exist only in -DV3A_ATTN_EXPERIMENTAL builds (tools/abl_build.sh)
         L.v3a_attention_set_kernel(which)
         o = torch.empty(B * N, d, device="cuda", dtype=torch.bfloat16)
-        run = lambda: ops.attention(q, k, vt, o, B=B, H=H, Nq=N, Nk=N, D=D, q_batch_stride=N * d, k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=N * d)
+        per = [int(x) for x in os.environ.get("V3A_ATTN_PERIOD", "0,0").split(",")]   # kv_period,kv_valid (the reconstruction's padded view layout)
+        run = lambda: ops.attention(q, k, vt, o, B=B, H=H, Nq=N, Nk=N, D=D, q_batch_stride=N * d, k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=N * d,
+                                    kv_period=per[0], kv_valid=per[1])
         for _ in range(20): run()
         torch.cuda.synchronize()
         times = []

@@ -263,13 +263,23 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
     if (RAG && p.kv_period > 0) {  // padded multi-frame token layout: mask the per-frame filler rows
       const int pos = (kt * KV) % p.kv_period;
       if (pos + KV > p.kv_valid) {  // some key of this tile is filler (always true for periods < 64)
+        if (p.kv_valid >= KV) {    // (then a 64-key tile meets at most one filler range) the filler rows [kv_valid, kv_period) of ONE frame meet the tile: tile-relative keys [lo, lo + n) (wave-uniform)
+          const int lo = p.kv_valid - pos - 16 * hi;
+          const unsigned n = (unsigned)(p.kv_period - p.kv_valid);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int o = (pos + 32 * t + 16 * hi + r) % p.kv_period;
-            if (o >= p.kv_valid) s[t][r] = -1e30f;
-          }
+            for (int r = 0; r < 16; ++r)
+              if ((unsigned)(32 * t + r - lo) < n) s[t][r] = -1e30f;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int o = (pos + 32 * t + 16 * hi + r) % p.kv_period;
+              if (o >= p.kv_valid) s[t][r] = -1e30f;
+            }
+        }
       }
     }
     float mx = s[0][0];
