@@ -213,7 +213,28 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-    {   // the two sub-tiles alternate (consecutive MFMAs never share an accumulator); fragment reads run PF ahead of their MFMA
+    constexpr bool PLAIN = !RAG && !KBIAS && !RELB;   // nothing touches S between the MFMAs and the row maximum
+    float mx0 = 0.f;
+    if constexpr (PLAIN) {   // sub-tile 0 first; its row maximum (8 v_max3) rides behind the MFMAs of sub-tile 1, one per MFMA
+      constexpr int NF = 2 * KS;
+      auto ldk = [&](int j) { return *(const bf16x8*)(sK + (j / KS) * 32 * KROWB + kfo[j % KS]); };
+      bf16x8 kf[NF];
+#pragma unroll
+      for (int j = 0; j < PF; ++j) kf[j] = ldk(j);
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        if (j + PF < NF) kf[j + PF] = ldk(j + PF);
+        s[j / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j % KS], s[j / KS], 0, 0, 0);
+        if (j > KS) {   // (not behind the first MFMA of sub-tile 1: sub-tile 0's last MFMA has just been issued)
+          static_assert(!PLAIN || KS == 8, "max schedule");
+          constexpr int FIRST[8] = {0, 3, 6, 8, 10, 12, 14, 16};   // 16 values over the 7 remaining MFMAs
+          const int e = j - KS - 1;
+#pragma unroll
+          for (int r = FIRST[e]; r < FIRST[e + 1]; ++r) mx0 = (r == 0) ? s[0][0] : fmaxf(mx0, s[0][r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {   // the two sub-tiles alternate (consecutive MFMAs never share an accumulator); fragment reads run PF ahead of their MFMA
       constexpr int NF = 2 * KS;
       auto ldk = [&](int j) { return *(const bf16x8*)(sK + (j & 1) * 32 * KROWB + kfo[j >> 1]); };
       bf16x8 kf[NF];
@@ -282,9 +303,11 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
         }
       }
     }
-    float mx = s[0][0];
+    float mx = PLAIN ? mx0 : s[0][0];
+    if constexpr (!PLAIN) {
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
     {   // max over the two lane halves (the two 16-key halves of a query's row) without the LDS round trip of ds_bpermute in the middle of
