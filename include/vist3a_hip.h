@@ -144,7 +144,8 @@ typedef struct {
   int ldq, ldk, ldvt, ldo;                                  /* elements */
   int B, H, Nq, Nk, D;
   float scale;                                              /* softmax scale, normally D^-0.5 */
-  int kv_period, kv_valid;  /* kv_period > 0: key k participates only if (k % kv_period) < kv_valid (per-frame row padding) */
+  int kv_period, kv_valid;  /* kv_period > 0: key k participates only if (k % kv_period) < kv_valid (per-frame row padding);
+                               not together with rel_bias / key_bias (V3A_ERR_ARG) */
   const float* rel_bias;    /* optional (D = 64 only): additive bias by relative position, fp32 [H][rel_bias_stride], entry
                              * (key - query + rel_bias_center) is added to scale*q.k — T5/UMT5 relative attention bias */
   int rel_bias_stride, rel_bias_center;

@@ -1,5 +1,10 @@
-"""Time + check the DiT self-attention launch (B=2, H=12, N=4096, D=128): kernel 1 (128-query workgroups, three per CU) against kernel 2
-(256-query workgroups, one wave per SIMD, 64 queries per wave) in ONE process; outputs must be bit-identical."""
+"""Time + check the flash-attention launch (default: the DiT self-attention, B=2, H=12, N=4096, D=128) on seeded N(0, 1/4) data.
+  python tools/attn_time.py 2x12x4096 2x12x6144          shapes as BxHxN
+  V3A_LIB=<other build>                                   A/B against another library build in a second process (vist3a_amd/lib.py)
+  V3A_ATTN_SAVE=/tmp/prefix                               first process saves the output, later ones compare bit-for-bit with it and
+                                                          print, for differing rows, which build is closer to an fp64 softmax
+  V3A_ATTN_D=64  V3A_ATTN_PERIOD=1032,1029                the reconstruction's head dim / padded view layout (kv_period, kv_valid)
+  V3A_ATTN_STUDY=1                                        also run the one-wave-per-SIMD study kernels 2 / 3 (-DV3A_ATTN_EXPERIMENTAL builds)"""
 import sys, json, os
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -18,12 +23,15 @@ for B, H, N in shapes:
     for b in range(B):
         vt[:, b * N:(b + 1) * N] = v[b * N:(b + 1) * N].t()
     outs = {}
-    for which in ((1, 2, 3) if os.environ.get("V3A_ATTN_STUDY") else (1,)):   # 2 / 3 exist only in -DV3A_ATTN_EXPERIMENTAL builds (tools/abl_build.sh)
+    for which in ((1, 2, 3) if os.environ.get("V3A_ATTN_STUDY") else (1,)):
         L.v3a_attention_set_kernel(which)
         o = torch.empty(B * N, d, device="cuda", dtype=torch.bfloat16)
         per = [int(x) for x in os.environ.get("V3A_ATTN_PERIOD", "0,0").split(",")]   # kv_period,kv_valid (the reconstruction's padded view layout)
-        run = lambda: ops.attention(q, k, vt, o, B=B, H=H, Nq=N, Nk=N, D=D, q_batch_stride=N * d, k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=N * d,
-                                    kv_period=per[0], kv_valid=per[1])
+        nk = int(os.environ.get("V3A_ATTN_NK", N))   # cross-attention: fewer keys than queries, with a per-key bias (the merged padding key)
+        kb = torch.zeros(B, (nk + 63) // 64 * 64, device="cuda") if os.environ.get("V3A_ATTN_NK") else None
+        if kb is not None: kb[:, nk - 1] = 6.0
+        run = lambda: ops.attention(q, k, vt, o, B=B, H=H, Nq=N, Nk=nk, D=D, q_batch_stride=N * d, k_batch_stride=N * d, vt_batch_stride=N, o_batch_stride=N * d,
+                                    kv_period=per[0], kv_valid=per[1], key_bias=kb)
         for _ in range(20): run()
         torch.cuda.synchronize()
         times = []

@@ -30,6 +30,9 @@
 #include "common.h"
 #include "../../include/vist3a_hip.h"
 
+#ifndef V3A_ATTN_PRIO
+#define V3A_ATTN_PRIO 2   // bit 0: s_setprio 1 around the S phase, bit 1: around the PV phase (MFMAs + interleaved softmax): 194.7 / 193.8 / 189.4 / 191.2 us for 0 / 1 / 2 / 3
+#endif
 #ifndef V3A_ATTN_PF
 #define V3A_ATTN_PF 2
 #endif
@@ -63,9 +66,7 @@ struct AttnP {
 //   V1 = true : K double-, V^T SINGLE-buffered (48 KB) and fetched under S and the softmax of its own tile, THREE workgroups per CU -
 //               the DiT's 98304 query rows are exactly 12 waves of 32 per CU (3 x 4 waves is one full round where 2 x 4 leaves a
 //               half-empty second one); one extra barrier per tile orders the V^T landing before the PV MFMAs.
-// RAG = false ("plain"): the caller guarantees Nk % 64 == 0, kv_period == 0 and kv_seg == 0 - the ragged-tile DMA path, the tail mask, the
-// filler-row mask and the segment arithmetic are compiled out (as never-taken branches they cost the DiT self-attention 2 %: 100 -> 73 SGPRs).
-template <int D, int NW, bool RELB, bool KBIAS, bool V1, bool RAG = true>
+template <int D, int NW, bool RELB, bool KBIAS, bool V1>
 __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const AttnP p) {
   constexpr int KSTRIDE = V1 ? 64 * D * 2 : 64 * D * 2 + D * 128;   // distance between the two K buffers
   constexpr int KV = 64;                 // keys per tile
@@ -86,7 +87,329 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, l31 = lane & 31;
-  constexpr int PF = V3A_ATTN_PF;   // LDS fragment reads in flight ahead of the MFMA that consumes them
+
+  // block -> (batch, head, query block); consecutive blocks of one (batch, head) share K/V in L2:
+  // hardware places block b on XCD b%8, so make the q-block index vary slowest across XCD lanes.
+  const int S = p.kv_split > 1 ? p.kv_split : 1;
+  const int nqb = (p.Nq + NW * 32 - 1) / (NW * 32);
+  const int bid0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid0 % S, bid = bid0 / S;
+  const int bh = bid / nqb, qb = bid % nqb;
+  const int b = bh / p.H, h = bh % p.H;
+  const int q0 = qb * (NW * 32) + wave * 32;
+
+  const char* Qb = p.q + ((size_t)b * p.q_bs + (size_t)h * D) * 2;
+  const char* Kb = p.k + ((size_t)b * p.k_bs + (size_t)h * D) * 2;
+  const char* Vb = p.vt + ((size_t)h * D * p.ldvt + (size_t)b * p.vt_bs) * 2;
+
+  // ---- Q fragments (B operand): lane (q = l31, hi) slot j <-> d = 16*ks + 8*hi + j ----
+  bf16x8 qf[KS];
+  {
+    int qr = q0 + l31;
+    qr = qr < p.Nq ? qr : p.Nq - 1;
+    const char* qp = Qb + (size_t)qr * p.ldq * 2 + hi * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
+  }
+
+  // ---- DMA sources ----
+  const char* kp[KINS];
+  const char* vp[VINS];
+  int krow[KINS];
+#pragma unroll
+  for (int j = 0; j < KINS; ++j) {
+    const int g = j * NW + wave;
+    const int r = g * KRPI + lane / KCPR;
+    const int c = lane % KCPR;
+    const int f = (KCPR == 16) ? (r & 15) : ((r >> 1) & 7);
+    krow[j] = r;
+    kp[j] = Kb + (size_t)(c ^ f) * 16;  // + row*ldk*2 added per tile (row clamp depends on tile)
+  }
+#pragma unroll
+  for (int j = 0; j < VINS; ++j) {
+    const int g = j * NW + wave;
+    const int r = g * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    vp[j] = Vb + ((size_t)r * p.ldvt + c * 8) * 2;
+  }
+  // with kv_seg (sequence-parallel: K / V^T are read straight from the all-gathered per-rank slabs, no reassembly copy) a 64-key
+  // tile lies inside one segment: its wave-uniform base moves by (k_seg - kv_seg * ldk) / (vt_seg - kv_seg) per segment crossed
+  auto stage_k = [&](int s, int kt) {
+    char* sb = smem + s * KSTRIDE;
+    const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.k_seg - (long)p.kv_seg * p.ldk) * 2 : 0;
+#pragma unroll
+    for (int j = 0; j < KINS; ++j) {
+      int row = kt * KV + krow[j];
+      row = row < p.Nk ? row : p.Nk - 1;
+      glds16(kp[j] + (size_t)row * p.ldk * 2 + so, sb + (j * NW + wave) * 1024);
+    }
+  };
+  auto stage_v = [&](int s, int kt) {
+    char* sv = V1 ? smem + 2 * KTILE : smem + s * KSTRIDE + KTILE;
+    const size_t so = p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.vt_seg - p.kv_seg) * 2 : 0;
+#pragma unroll
+    for (int j = 0; j < VINS; ++j) glds16(vp[j] + (size_t)kt * KV * 2 + so, sv + (j * NW + wave) * 1024);
+  };
+
+  // ---- fragment read offsets ----
+  // K (A operand of QK^T): MFMA row i = l31 <-> key pi(i) inside the 32-key sub-tile
+  const int pi = (l31 & 3) + 4 * (l31 >> 3) + 16 * ((l31 >> 2) & 1);
+  int kfo[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int cc = 2 * ks + hi;
+    const int f = (KCPR == 16) ? (pi & 15) : ((pi >> 1) & 7);  // (pi+32)&15 == pi&15, ((pi+32)>>1)&7 == (pi>>1)&7
+    kfo[ks] = pi * KROWB + ((cc ^ f) << 4);
+  }
+  // V^T (A operand of PV): row d = l31 (+32*dt), chunk = 4*t32 + 2*hi + ks2
+  int vfo[4];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    const int t32 = c4 >> 1, ks2 = c4 & 1;
+    const int cc = 4 * t32 + 2 * hi + ks2;
+    vfo[c4] = l31 * 128 + ((cc ^ ((l31 >> 1) & 7)) << 4);
+  }
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = p.scale_log2e;
+
+  const int nkt = (p.Nk + KV - 1) / KV;
+  const int kt0 = (int)((long)split * nkt / S), kt1 = (int)((long)(split + 1) * nkt / S);   // this workgroup's key tiles
+  stage_k(0, kt0);
+  if constexpr (!V1) stage_v(0, kt0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    if constexpr (V1) {
+      stage_v(0, kt);                               // V^T of this tile: lands under S and the softmax
+      if (kt + 1 < kt1) stage_k(cur ^ 1, kt + 1);   // K of the next tile
+    } else if (kt + 1 < kt1) {
+      stage_k(cur ^ 1, kt + 1);
+      stage_v(cur ^ 1, kt + 1);
+    }
+    const char* sK = smem + cur * KSTRIDE;
+    const char* sV = V1 ? smem + 2 * KTILE : sK + KTILE;
+
+    // S^T = K . Q^T  (two 32-key sub-tiles)
+    f32x16 s[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(sK + t * 32 * KROWB + kfo[ks]);
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+      }
+    }
+    // lane (q = l31, hi) now holds keys kt*64 + 32*t + 16*hi + r, r = 0..15
+    if (KBIAS && (kt + 1) * KV > p.kbias_first) {  // per-key additive bias (cross-attention over a zero-padded prompt: the identical padding keys are
+                            // merged into ONE key carrying log(count)); 16 consecutive entries per sub-tile and lane
+      const float* kb = p.kbias + (size_t)b * p.kbias_stride + kt * KV + 16 * hi;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * KV + 32 * t + 16 * hi + r < p.Nk) s[t][r] += kb[32 * t + r] * p.inv_scale;
+    }
+    if constexpr (RELB) {  // T5-style relative position bias (UMT5 text encoder): 16 consecutive table entries per sub-tile
+      const float* tb = p.relb + (size_t)h * p.relb_stride + p.relb_center + (kt * KV + 16 * hi) - min(q0 + l31, p.Nq - 1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * KV + 32 * t + 16 * hi + r;
+          if (key < p.Nk) s[t][r] += tb[32 * t + r] * p.inv_scale;
+        }
+    }
+    if (kt == nkt - 1 && (p.Nk & (KV - 1))) {
+      const int kb = kt * KV + 16 * hi;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kb + 32 * t + r >= p.Nk) s[t][r] = -1e30f;
+    }
+    // padded multi-frame token layout: mask the per-frame filler rows (not in the bias instantiations - v3a_attention_fwd_bf16 rejects the
+    // combination: beside the bias loops this block sent hipcc into a 12 k-instruction, 3 KB-scratch body)
+    if (!RELB && !KBIAS && p.kv_period > 0) {
+      const int pos = (kt * KV) % p.kv_period;
+      if (pos + KV > p.kv_valid) {  // some key of this tile is filler (always true for periods < 64)
+        // the filler rows [kv_valid, kv_period) of each frame the tile meets are tile-relative keys [st, st + n), wave-uniform: one unsigned
+        // compare per key and range (one range when kv_valid >= 64; round 3: the per-key modulo form cost the reconstruction's global
+        // attention 6 %, this one 2 %)
+        const unsigned n = (unsigned)(p.kv_period - p.kv_valid);
+        for (int st = p.kv_valid - pos; st < KV; st += p.kv_period) {
+          const int lo = st - 16 * hi;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if ((unsigned)(32 * t + r - lo) < n) s[t][r] = -1e30f;
+        }
+      }
+    }
+    float mx = s[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // Deferred rescale: m_run is the REFERENCE of the exponentials, not necessarily the running maximum.  It moves (and l / O are
+    // rescaled) only when some lane's maximum outgrew it by more than 2^DEFER; until then p = 2^((s - m_run) c) <= 2^DEFER, which
+    // costs bf16 no precision, and the 64 accumulator multiplies per tile are skipped (on random scores: every tile but the first
+    // few).  O / l at the end is invariant to the reference.
+    constexpr float DEFER = 8.0f;
+    const float m_new = fmaxf(m_run, mx);
+    const bool rescale = __builtin_amdgcn_ballot_w64((m_new - m_run) * c > DEFER) != 0;
+    float alpha = 1.0f;
+    if (rescale) {
+      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+    }
+    const float mc = m_run * c;
+    float psum = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], c, -mc));   // an explicit FMA: left to contraction hipcc fused 31 of the 32 and
+                                                                            // the hand-scheduled plain kernel all 32 - the two must agree bit for bit
+        psum += pv[r];
+      }
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        u32x4 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(pv[8 * ks2 + 2 * e], pv[8 * ks2 + 2 * e + 1]);
+        pf[2 * t + ks2] = __builtin_bit_cast(bf16x8, pk);
+      }
+    }
+    l_run = l_run * alpha + psum;
+    if (rescale) {
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    if constexpr (V1) {
+      // V^T pieces were issued before the K pieces: leave the K prefetch in flight
+      if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's V^T pieces have landed
+    }
+    // O^T += V^T . P^T
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        const bf16x8 vf = *(const bf16x8*)(sV + i * 4096 + vfo[c4]);
+        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[c4], oacc[i], 0, 0, 0);
+      }
+    }
+    // lgkmcnt(0) is essential: hipcc sinks the last PV MFMA (and the wait for its V^T fragment read) BELOW the barrier, so a
+    // wave would pass it with an LDS read of the single V^T buffer still in flight while a faster wave's next-tile DMA
+    // overwrites that buffer (seen as run-to-run differences in whole 32-row groups)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- finish: combine the two key halves of l, normalise, park O as [q][d] in LDS, store rows ----
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (S > 1) {   // split keys: unnormalised partial O (fp32) + its reference and sum; attn_combine_kernel finishes the softmax
+    const int qr = q0 + l31;
+    if (qr < p.Nq) {
+      const size_t row = ((size_t)split * p.B + b) * p.Nq + qr;
+      float* po = p.ws_o + (row * p.H + h) * D;
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = oacc[i][g * 4 + e];
+          *(f32x4*)(po + i * 32 + g * 8 + hi * 4) = v;
+        }
+      if (hi == 0) {
+        float* pm = p.ws_ml + (row * p.H + h) * 2;
+        pm[0] = m_run; pm[1] = l_run;
+      }
+    }
+    return;
+  }
+  const float inv = 1.0f / l_run;
+  char* reg = smem + wave * (32 * OPITCH);
+#pragma unroll
+  for (int i = 0; i < DT; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = i * 32 + g * 8 + hi * 4;
+      u32x2 pk;
+      pk[0] = pack_bf16x2(oacc[i][g * 4 + 0] * inv, oacc[i][g * 4 + 1] * inv);
+      pk[1] = pack_bf16x2(oacc[i][g * 4 + 2] * inv, oacc[i][g * 4 + 3] * inv);
+      *(u32x2*)(reg + l31 * OPITCH + d * 2) = pk;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  constexpr int CH = D / 8;  // 16-B chunks per output row
+  char* Ob = p.o + ((size_t)b * p.o_bs + (size_t)h * D) * 2;
+#pragma unroll
+  for (int it = 0; it < 32 * CH / 64; ++it) {
+    const int idx = it * 64 + lane;
+    const int ql = idx / CH, ch = idx % CH;
+    const u32x2 lo = *(const u32x2*)(reg + ql * OPITCH + ch * 16);
+    const u32x2 hi2 = *(const u32x2*)(reg + ql * OPITCH + ch * 16 + 8);
+    const int qr = q0 + ql;
+    if (qr < p.Nq) {
+      u32x4 v;
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = hi2[0]; v[3] = hi2[1];
+      *(u32x4*)(Ob + ((size_t)qr * p.ldo) * 2 + ch * 16) = v;
+    }
+  }
+}
+
+
+// The DiT self-attention's own instantiation ("plain": hd = 128, Nk % 64 == 0, no key mask / bias / segments; K double-, V^T single-buffered,
+// three workgroups per CU) - the same arithmetic as attn_fwd_kernel<128, NW, false, false, true> above with the loop scheduled by hand
+// (round 3): wave-uniform DMA bases + one 32-bit lane offset, LDS fragment reads PF ahead of their MFMA, sub-tile
+// 0's row maximum behind the MFMAs of sub-tile 1, P in four 16-key chunks exponentiated behind the PV MFMAs of the previous chunk,
+// s_setprio 1 around the PV phase, cross-half maximum by v_permlane32_swap.  Everything else (ragged / masked / biased / segmented keys,
+// hd = 64, split keys' general forms) stays on attn_fwd_kernel, whose loop hipcc schedules: pinning it there cost registers (Q fragments
+// in scratch at 168 VGPRs, hd = 64 lost a wave per SIMD) and kept the bias-table loads from being hoisted (cross-attention 21.6 -> 26.5 us).
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 3) void attn_fwd_plain_kernel(const AttnP p) {
+  constexpr bool V1 = true;
+  static_assert(D == 128 && NW == 4, "the DiT self-attention form");
+  constexpr int KSTRIDE = V1 ? 64 * D * 2 : 64 * D * 2 + D * 128;   // distance between the two K buffers
+  constexpr int KV = 64;                 // keys per tile
+  constexpr int KROWB = D * 2;           // bytes per K row in LDS
+  constexpr int KCPR = KROWB / 16;       // 16-B chunks per K row (16 or 8)
+  constexpr int KRPI = 64 / KCPR;        // K rows per DMA instruction (4 or 8)
+  constexpr int KTILE = KV * KROWB;      // bytes
+  constexpr int VTILE = D * 128;         // D rows x 64 keys x 2 B
+  constexpr int STAGE = KTILE + VTILE;
+  constexpr int KINS = KTILE / 1024 / NW;  // DMA instructions per wave per tile (K)
+  constexpr int VINS = VTILE / 1024 / NW;
+  constexpr int KS = D / 16;             // k-steps of QK^T
+  constexpr int DT = D / 32;             // 32-row d tiles of O^T
+  constexpr int OPITCH = D * 2 + 8;
+  static_assert(KTILE % (1024 * NW) == 0 && VTILE % (1024 * NW) == 0, "tile/wave split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, l31 = lane & 31;
+  constexpr int PF = V3A_ATTN_PF;   // plain instantiation: LDS fragment reads in flight ahead of the MFMA that consumes them
 
   // block -> (batch, head, query block); consecutive blocks of one (batch, head) share K/V in L2:
   // hardware places block b on XCD b%8, so make the q-block index vary slowest across XCD lanes.
@@ -114,49 +437,26 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
 
   // ---- DMA sources ----
   // A DMA address = wave-uniform 64-bit base (SGPRs: batch / head slab + tile + piece) + ONE per-lane 32-bit byte offset (row inside the
-  // piece, swizzled 16-byte chunk): two v_lshl_add_u64 per piece and two VGPRs per operand for the whole loop.  (Round 2 kept KINS + VINS
-  // per-lane 64-bit pointers and rebuilt row / clamp / row x ldk per piece: 47 VALU instructions per tile incl. eight quarter-rate
-  // v_mul_lo_u32, and every attempt to hoist them spilled at the 168-register allocation.)  Only the ragged LAST tile needs per-lane row
-  // clamps: it takes the slow path below, once per workgroup, recomputed from the lane id so that it holds no register across the loop.
-  constexpr int NOFF = (KCPR == 16 && (NW * KRPI) % 16 != 0) ? 2 : 1;   // the swizzle term repeats every 16 rows (D = 128) / is piece-invariant
-  unsigned kvo[NOFF], vvo;
+  // piece, swizzled 16-byte chunk): one v_lshl_add_u64 per piece and two VGPRs per operand for the whole loop.  (attn_fwd_kernel keeps KINS +
+  // VINS per-lane 64-bit pointers and rebuilds row / clamp / row x ldk per piece - it has ragged last tiles to clamp: 47 VALU instructions
+  // per tile incl. eight quarter-rate v_mul_lo_u32.)
+  static_assert((NW * KRPI) % 16 == 0, "the swizzle term must not depend on the piece");
+  unsigned kvo, vvo;
   {
     const int r0 = wave * KRPI + lane / KCPR, c = lane % KCPR;
-#pragma unroll
-    for (int o = 0; o < NOFF; ++o) {
-      const int r = o * NW * KRPI + r0;
-      const int f = (KCPR == 16) ? (r & 15) : ((r >> 1) & 7);
-      kvo[o] = (unsigned)((c ^ f) * 16) + (unsigned)r0 * (unsigned)p.ldk * 2u;
-    }
+    kvo = (unsigned)((c ^ (r0 & 15)) * 16) + (unsigned)r0 * (unsigned)p.ldk * 2u;
     const int rv = wave * 8 + (lane >> 3);                                // V^T piece stride NW * 8 rows: (rv >> 1) & 7 is piece-invariant
     vvo = ((unsigned)rv * (unsigned)p.ldvt + (unsigned)(((lane & 7) ^ ((rv >> 1) & 7)) * 8)) * 2u;
   }
-  // with kv_seg (sequence-parallel: K / V^T are read straight from the all-gathered per-rank slabs, no reassembly copy) a 64-key
-  // tile lies inside one segment: its wave-uniform base moves by (k_seg - kv_seg * ldk) / (vt_seg - kv_seg) per segment crossed
   auto stage_k = [&](int s, int kt) {
     char* sb = smem + s * KSTRIDE;
-    const size_t so = RAG && p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.k_seg - (long)p.kv_seg * p.ldk) * 2 : 0;
-    if (RAG && (kt + 1) * KV > p.Nk) {   // ragged last tile: rows past Nk - 1 re-read row Nk - 1 (masked to -inf below)
-      int ln = lane;
-      asm volatile("" : "+v"(ln));   // keeps this block's address arithmetic inside the block
+    const size_t base = (size_t)kt * ((size_t)KV * p.ldk * 2), piece = (size_t)(NW * KRPI) * p.ldk * 2;
 #pragma unroll
-      for (int j = 0; j < KINS; ++j) {
-        const int r = (j * NW + wave) * KRPI + ln / KCPR, c = ln % KCPR;
-        const int f = (KCPR == 16) ? (r & 15) : ((r >> 1) & 7);
-        int row = kt * KV + r;
-        row = row < p.Nk ? row : p.Nk - 1;
-        glds16(Kb + (size_t)(c ^ f) * 16 + (size_t)row * p.ldk * 2 + so, sb + (j * NW + wave) * 1024);
-      }
-    } else {
-      const size_t base = (size_t)kt * ((size_t)KV * p.ldk * 2) + so, piece = (size_t)(NW * KRPI) * p.ldk * 2;
-#pragma unroll
-      for (int j = 0; j < KINS; ++j) glds16(Kb + (base + j * piece) + (size_t)kvo[j % NOFF], sb + (j * NW + wave) * 1024);
-    }
+    for (int j = 0; j < KINS; ++j) glds16(Kb + (base + j * piece) + (size_t)kvo, sb + (j * NW + wave) * 1024);
   };
   auto stage_v = [&](int s, int kt) {
-    char* sv = V1 ? smem + 2 * KTILE : smem + s * KSTRIDE + KTILE;
-    const size_t so = RAG && p.kv_seg > 0 ? (size_t)((kt * KV) / p.kv_seg) * (size_t)(p.vt_seg - p.kv_seg) * 2 : 0;
-    const size_t base = (size_t)kt * KV * 2 + so, piece = (size_t)(NW * 8) * p.ldvt * 2;
+    char* sv = smem + 2 * KTILE;
+    const size_t base = (size_t)kt * KV * 2, piece = (size_t)(NW * 8) * p.ldvt * 2;
 #pragma unroll
     for (int j = 0; j < VINS; ++j) glds16(Vb + (base + j * piece) + (size_t)vvo, sv + (j * NW + wave) * 1024);
   };
@@ -213,9 +513,10 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-    constexpr bool PLAIN = !RAG && !KBIAS && !RELB;   // nothing touches S between the MFMAs and the row maximum
+    constexpr bool PLAIN = true;   // nothing touches S between the MFMAs and the row maximum
     float mx0 = 0.f;
-    if constexpr (PLAIN) {   // sub-tile 0 first; its row maximum (8 v_max3) rides behind the MFMAs of sub-tile 1, one per MFMA
+    if constexpr (V3A_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(1);
+    {   // sub-tile 0 first; its row maximum (8 v_max3) rides behind the MFMAs of sub-tile 1, one per MFMA
       constexpr int NF = 2 * KS;
       auto ldk = [&](int j) { return *(const bf16x8*)(sK + (j / KS) * 32 * KROWB + kfo[j % KS]); };
       bf16x8 kf[NF];
@@ -234,80 +535,10 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else {   // the two sub-tiles alternate (consecutive MFMAs never share an accumulator); fragment reads run PF ahead of their MFMA
-      constexpr int NF = 2 * KS;
-      auto ldk = [&](int j) { return *(const bf16x8*)(sK + (j & 1) * 32 * KROWB + kfo[j >> 1]); };
-      bf16x8 kf[NF];
-#pragma unroll
-      for (int j = 0; j < PF; ++j) kf[j] = ldk(j);
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        if (j + PF < NF) kf[j + PF] = ldk(j + PF);
-        s[j & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[j], qf[j >> 1], s[j & 1], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
-#pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        if (j + PF < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      }
     }
-    // lane (q = l31, hi) now holds keys kt*64 + 32*t + 16*hi + r, r = 0..15
-    if (KBIAS && (kt + 1) * KV > p.kbias_first) {  // per-key additive bias (cross-attention over a zero-padded prompt: the identical padding keys are
-                            // merged into ONE key carrying log(count)); 16 consecutive entries per sub-tile and lane
-      const float* kb = p.kbias + (size_t)b * p.kbias_stride + kt * KV + 16 * hi;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt * KV + 32 * t + 16 * hi + r < p.Nk) s[t][r] += kb[32 * t + r] * p.inv_scale;
-    }
-    if constexpr (RELB) {  // T5-style relative position bias (UMT5 text encoder): 16 consecutive table entries per sub-tile
-      const float* tb = p.relb + (size_t)h * p.relb_stride + p.relb_center + (kt * KV + 16 * hi) - min(q0 + l31, p.Nq - 1);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * KV + 32 * t + 16 * hi + r;
-          if (key < p.Nk) s[t][r] += tb[32 * t + r] * p.inv_scale;
-        }
-    }
-    if (RAG && kt == nkt - 1 && (p.Nk & (KV - 1))) {
-      asm volatile("");   // a real branch: if-converted, these were 31 v_cndmask on every tile
-      const int kb = kt * KV + 16 * hi;
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kb + 32 * t + r >= p.Nk) s[t][r] = -1e30f;
-    }
-    if (RAG && p.kv_period > 0) {  // padded multi-frame token layout: mask the per-frame filler rows
-      const int pos = (kt * KV) % p.kv_period;
-      if (pos + KV > p.kv_valid) {  // some key of this tile is filler (always true for periods < 64)
-        if (p.kv_valid >= KV) {    // (then a 64-key tile meets at most one filler range) the filler rows [kv_valid, kv_period) of ONE frame meet the tile: tile-relative keys [lo, lo + n) (wave-uniform)
-          const int lo = p.kv_valid - pos - 16 * hi;
-          const unsigned n = (unsigned)(p.kv_period - p.kv_valid);
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if ((unsigned)(32 * t + r - lo) < n) s[t][r] = -1e30f;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int o = (pos + 32 * t + 16 * hi + r) % p.kv_period;
-              if (o >= p.kv_valid) s[t][r] = -1e30f;
-            }
-        }
-      }
-    }
-    float mx = PLAIN ? mx0 : s[0][0];
-    if constexpr (!PLAIN) {
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-    }
+    if constexpr (V3A_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(0);
+    // lane (q = l31, hi) now holds keys kt*64 + 32*t + 16*hi + r, r = 0..15; no bias, no mask in this instantiation
+    float mx = mx0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
     {   // max over the two lane halves (the two 16-key halves of a query's row) without the LDS round trip of ds_bpermute in the middle of
@@ -337,53 +568,54 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
     }
     const float mc = m_run * c;
     float psum = 0.f;
-    // P in four 16-key chunks (= the four K-slices of the PV product), summed in key order: chunk c + 1 is exponentiated in the issue
-    // slots behind the MFMAs of chunk c (a wave issues in order: VALU work right behind an MFMA runs in its shadow)
-    u32x4 pw[4];
-    auto pquarter = [&](int c4, int q) {   // keys 2q, 2q + 1 of chunk c4: 2 x (fma, exp, add) + one pack = 7 VALU instructions
-      const int t = c4 >> 1, r0 = 8 * (c4 & 1) + 2 * q;
-      const float p0 = __builtin_amdgcn_exp2f(s[t][r0] * c - mc), p1 = __builtin_amdgcn_exp2f(s[t][r0 + 1] * c - mc);
-      psum += p0;
-      psum += p1;
-      pw[c4][q] = pack_bf16x2(p0, p1);
-    };
-    auto pchunk = [&](int c4) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pquarter(c4, q);
-    };
-    if (rescale) {
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-    }
-    pchunk(0);
-    if constexpr (V1) {
-      // V^T pieces were issued before the K pieces: leave the K prefetch in flight
-      if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // every wave's V^T pieces have landed
-    }
-    // O^T += V^T . P^T
     {
-      constexpr int NF = 4 * DT;
-      auto ldv = [&](int j) { return *(const bf16x8*)(sV + (j % DT) * 4096 + vfo[j / DT]); };
-      bf16x8 vf[NF];
+      // P in four 16-key chunks (= the four K-slices of the PV product), summed in key order: chunk c + 1 is exponentiated in the issue
+      // slots behind the MFMAs of chunk c (a wave issues in order: VALU work right behind an MFMA runs in its shadow)
+      u32x4 pw[4];
+      auto pquarter = [&](int c4, int q) {   // keys 2q, 2q + 1 of chunk c4: 2 x (fma, exp, add) + one pack = 7 VALU instructions
+        const int t = c4 >> 1, r0 = 8 * (c4 & 1) + 2 * q;
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r0], c, -mc)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r0 + 1], c, -mc));
+        psum += p0;
+        psum += p1;
+        pw[c4][q] = pack_bf16x2(p0, p1);
+      };
+      auto pchunk = [&](int c4) {
 #pragma unroll
-      for (int j = 0; j < PF; ++j) vf[j] = ldv(j);
+        for (int q = 0; q < 4; ++q) pquarter(c4, q);
+      };
+      if (rescale) {
 #pragma unroll
-      for (int j = 0; j < NF; ++j) {
-        if (j + PF < NF) vf[j + PF] = ldv(j + PF);
-        oacc[j % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], __builtin_bit_cast(bf16x8, pw[j / DT]), oacc[j % DT], 0, 0, 0);
-        if constexpr (DT == 4) {
-          if (j / DT + 1 < 4) pquarter(j / DT + 1, j % DT);
-        } else {   // two MFMAs per chunk (D = 64): half a chunk behind each
-          if (j / DT + 1 < 4) { pquarter(j / DT + 1, 2 * (j % DT)); pquarter(j / DT + 1, 2 * (j % DT) + 1); }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // exactly this order: read ahead, MFMA, its share of the next chunk's softmax
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
       }
+      pchunk(0);
+      if constexpr (V1) {
+        // V^T pieces were issued before the K pieces: leave the K prefetch in flight
+        if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KINS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave's V^T pieces have landed
+      }
+      // O^T += V^T . P^T
+      if constexpr (V3A_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(1);
+      {
+        constexpr int NF = 4 * DT;
+        auto ldv = [&](int j) { return *(const bf16x8*)(sV + (j % DT) * 4096 + vfo[j / DT]); };
+        bf16x8 vf[NF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) vf[j] = ldv(j);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          if (j + PF < NF) vf[j + PF] = ldv(j + PF);
+          oacc[j % DT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], __builtin_bit_cast(bf16x8, pw[j / DT]), oacc[j % DT], 0, 0, 0);
+          static_assert(!PLAIN || DT == 4, "one quarter chunk per MFMA");
+          if (j / DT + 1 < 4) pquarter(j / DT + 1, j % DT);
+          __builtin_amdgcn_sched_barrier(0);   // exactly this order: read ahead, MFMA, its share of the next chunk's softmax
+        }
+      }
+      if constexpr (V3A_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(0);
+      l_run = l_run * alpha + psum;
     }
-    l_run = l_run * alpha + psum;
     // lgkmcnt(0) is essential: hipcc sinks the last PV MFMA (and the wait for its V^T fragment read) BELOW the barrier, so a
     // wave would pass it with an LDS read of the single V^T buffer still in flight while a faster wave's next-tile DMA
     // overwrites that buffer (seen as run-to-run differences in whole 32-row groups)
@@ -450,7 +682,9 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
 // EXPERIMENTAL (compiled only with -DV3A_ATTN_EXPERIMENTAL; tools/abl_build.sh builds it): round-3 study of the one-wave-per-SIMD,
 // 64-queries-per-wave structure for the DiT self-attention.  NOT used by the product; kept because the measurements below decide
 // what the next attempt has to look like ("round 3"):
-//   attn_fwd64_kernel  (kernel 2): S -> softmax -> PV in sequence.  Bit-identical to the production kernel, deterministic.
+//   attn_fwd64_kernel  (kernel 2): S -> softmax -> PV in sequence.  Bit-identical to the ROUND-2 production kernel, deterministic (the
+//                      round-3 production loop computes all 32 exponent arguments of a tile as fused multiply-adds where hipcc had left one
+//                      of them as a packed multiply + subtract: 88 of 25 M outputs of the DiT launch move by one bf16 ulp).
 //                      B=2 H=16 N=4096 (two full rounds of 256-query workgroups): 270 us vs 280 us; the DiT's H=12 (1.5 rounds): 266 vs 203.
 //   attn_fwd64p_kernel (kernel 3): software-pipelined (S^T double-buffered in registers, finish-softmax(t) beside the S MFMAs of t+1,
 //                      start-softmax(t+1) beside the PV MFMAs of t).  251-258 us at H=16.  With the row-max exchange through
@@ -1140,14 +1374,18 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const AttnP p) {
   else *(unsigned short*)o = (unsigned short)(pack_bf16x2(acc[0] * inv, 0.f) & 0xffffu);
 }
 
-template <int D, int NW, bool RELB, bool KBIAS, bool V1, bool RAG = true>
+template <int D, int NW, bool RELB, bool KBIAS, bool V1, bool PLAIN = false>
 int launch_attn(const AttnP& p, int B, void* stream) {
   constexpr int KT = 64 * D * 2, VT = D * 128;
   constexpr int RING = V1 ? 2 * KT + VT : 2 * (KT + VT);
   constexpr int OBYTES = NW * 32 * (D * 2 + 8);
   constexpr int LDS = RING > OBYTES ? RING : OBYTES;
   static bool attr = false;
-  auto fn = attn_fwd_kernel<D, NW, RELB, KBIAS, V1, RAG>;
+  void (*fn)(const AttnP) = attn_fwd_kernel<D, NW, RELB, KBIAS, V1>;
+  if constexpr (PLAIN) {
+    static_assert(!PLAIN || (D == 128 && !RELB && !KBIAS && V1), "plain = the DiT self-attention form");
+    fn = attn_fwd_plain_kernel<D, NW>;
+  }
   if (!attr) {
     if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
       return V3A_ERR_LAUNCH;
@@ -1202,6 +1440,7 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
   if (!a->kv_seg && a->vt_batch_stride && a->vt_batch_stride < a->Nk && a->B > 1) return V3A_ERR_SHAPE;
   if (a->kv_seg > 0 && a->vt_batch_stride && a->vt_batch_stride < a->kv_seg && a->B > 1) return V3A_ERR_SHAPE;
   if (a->kv_period < 0 || (a->kv_period > 0 && (a->kv_valid <= 0 || a->kv_valid > a->kv_period))) return V3A_ERR_ARG;
+  if (a->kv_period > 0 && (a->rel_bias || a->key_bias)) return V3A_ERR_ARG;   // the key-period mask is not compiled into the bias kernels
   AttnP p = {};   // every optional feature off unless set below (the relative-bias launch returns before most of them)
   p.q = (const char*)a->q; p.k = (const char*)a->k; p.vt = (const char*)a->vt; p.o = (char*)a->o;
   p.q_bs = a->q_batch_stride; p.k_bs = a->k_batch_stride; p.vt_bs = a->vt_batch_stride; p.o_bs = a->o_batch_stride;
@@ -1242,7 +1481,7 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
     // workgroups double the count; per-wave arithmetic and key order are unchanged, so the output stays bit-identical
     const long wgs4 = (long)a->B * a->H * ((a->Nq + 127) / 128) * p.kv_split;
     if (wgs4 < 256) return launch_attn<128, 2, false, false, true>(p, a->B, stream);
-    if (a->Nk % 64 == 0 && !a->kv_period && !a->kv_seg) return launch_attn<128, 4, false, false, true, false>(p, a->B, stream);
+    if (a->Nk % 64 == 0 && !a->kv_period && !a->kv_seg) return launch_attn<128, 4, false, false, true, true>(p, a->B, stream);
     return launch_attn<128, 4, false, false, true>(p, a->B, stream);
   }
   return launch_attn<64, 4, false, false, false>(p, a->B, stream);  // recon (hd = 64): the 3-per-CU schedule measured no gain there
