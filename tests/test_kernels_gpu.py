@@ -242,6 +242,27 @@ def test_attention_hd128_dit_self_attention_shape(hip_lib, parity):
     assert r < TOL_ATTN_EXACT and re < TOL_ATTN_CONTRACT, (r, re)
 
 
+@pytest.mark.parametrize("B,H,N", [(2, 12, 4096), (1, 3, 2048)])
+def test_attention_plain_kernel_is_bit_identical_to_the_general_kernel(hip_lib, parity, B, H, N):
+    """The DiT self-attention runs on its own hand-scheduled kernel (attn_fwd_plain_kernel, csrc/attention.hip) when Nk % 64 == 0 and no
+    mask / bias / segment option is set; the same launch described as ONE key segment (kv_seg = Nk) takes the general, hipcc-scheduled
+    attn_fwd_kernel.  Same arithmetic, same order, explicit FMAs: every output bit must agree (the sequence-parallel forward, which reads
+    gathered slabs through kv_seg, relies on it), and both must be deterministic."""
+    D = 128
+    g = torch.Generator(device=dev).manual_seed(N + H)
+    q, k, v, vt, nkp = _attn_inputs(B, H, N, N, D, g)
+    plain, plain2 = _run_attn(q, k, vt, nkp, B, H, N, N, D), _run_attn(q, k, vt, nkp, B, H, N, N, D)
+    if B == 1:
+        general = _run_attn(q, k, vt, nkp, B, H, N, N, D, kv_seg=N, k_seg_stride=N * H * D, vt_seg_stride=nkp)
+    else:   # segments are per batch item: compare item by item
+        general = torch.cat([_run_attn(q[b:b + 1], k[b:b + 1], vt[:, b * nkp:(b + 1) * nkp], nkp, 1, H, N, N, D, kv_seg=N, k_seg_stride=N * H * D,
+                                       vt_seg_stride=nkp) for b in range(B)], 0)
+    same = bool(torch.equal(plain, general))
+    parity("attention_plain_vs_general_kernel", B=B, H=H, N=N, bit_identical=same, deterministic=bool(torch.equal(plain, plain2)))
+    assert torch.equal(plain, plain2)
+    assert same, f"{int((plain != general).sum())} of {plain.numel()} outputs differ"
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,S", [(1, 12, 1024, 4096, 8), (2, 12, 512, 4096, 5), (1, 40, 1000, 4096 + 37, 3), (2, 3, 130, 200, 4)])
 def test_attention_key_split_matches_unsplit_and_fp32(hip_lib, parity, B, H, Nq, Nk, S):
     """kv_split (sequence-parallel shards: few query rows against all keys): partial softmaxes over S key ranges merged by the second

@@ -33,6 +33,12 @@
 #ifndef V3A_ATTN_PRIO
 #define V3A_ATTN_PRIO 2   // bit 0: s_setprio 1 around the S phase, bit 1: around the PV phase (MFMAs + interleaved softmax): 194.7 / 193.8 / 189.4 / 191.2 us for 0 / 1 / 2 / 3
 #endif
+#ifndef V3A_ATTN_PRIO_S_LEVEL
+#define V3A_ATTN_PRIO_S_LEVEL 1
+#endif
+#ifndef V3A_ATTN_PRIO_PV_LEVEL
+#define V3A_ATTN_PRIO_PV_LEVEL 1
+#endif
 #ifndef V3A_ATTN_PF
 #define V3A_ATTN_PF 2
 #endif
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_plain_kernel(const AttnP 
       for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
     constexpr bool PLAIN = true;   // nothing touches S between the MFMAs and the row maximum
     float mx0 = 0.f;
-    if constexpr (V3A_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (V3A_ATTN_PRIO & 1) __builtin_amdgcn_s_setprio(V3A_ATTN_PRIO_S_LEVEL);
     {   // sub-tile 0 first; its row maximum (8 v_max3) rides behind the MFMAs of sub-tile 1, one per MFMA
       constexpr int NF = 2 * KS;
       auto ldk = [&](int j) { return *(const bf16x8*)(sK + (j / KS) * 32 * KROWB + kfo[j % KS]); };
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_plain_kernel(const AttnP 
         __builtin_amdgcn_s_barrier();  // every wave's V^T pieces have landed
       }
       // O^T += V^T . P^T
-      if constexpr (V3A_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(1);
+      if constexpr (V3A_ATTN_PRIO & 2) __builtin_amdgcn_s_setprio(V3A_ATTN_PRIO_PV_LEVEL);
       {
         constexpr int NF = 4 * DT;
         auto ldv = [&](int j) { return *(const bf16x8*)(sV + (j % DT) * 4096 + vfo[j / DT]); };
