@@ -19,7 +19,8 @@ for k, d in acc.items():
     if "GRBM_GUI_ACTIVE" not in d or d["GRBM_GUI_ACTIVE"] == 0: continue
     util = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (d["GRBM_GUI_ACTIVE"] / 8 * 256 * 4)  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
     out[k[:110]] = dict(dispatches=n[(k, "GRBM_GUI_ACTIVE")], gui_active_cycles_total=d["GRBM_GUI_ACTIVE"], mfma_busy_cycles_total=d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), mfma_util=round(util, 4))
-top = dict(sorted(out.items(), key=lambda kv: -kv[1]["gui_active_cycles_total"])[:12])
+ours = {k: v for k, v in out.items() if "anonymous namespace" in k and "at::native" not in k}   # every kernel of csrc/, not only the top rows
+top = dict(sorted(ours.items(), key=lambda kv: -kv[1]["gui_active_cycles_total"])[:16])
 open("$R/gpurun_out/pmc_mfma.json", "w").write(json.dumps(top, indent=1))
 print(json.dumps(top, indent=1))
 PY

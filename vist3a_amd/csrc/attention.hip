@@ -31,13 +31,14 @@
 #include "../../include/vist3a_hip.h"
 
 #ifndef V3A_ATTN_PRIO
-#define V3A_ATTN_PRIO 2   // bit 0: s_setprio 1 around the S phase, bit 1: around the PV phase (MFMAs + interleaved softmax): 194.7 / 193.8 / 189.4 / 191.2 us for 0 / 1 / 2 / 3
+#define V3A_ATTN_PRIO 3   // bit 0: s_setprio around the S phase, bit 1: around the PV phase (MFMAs + interleaved softmax).  One box: 194.7 us without, 193.8 S only,
+                          // 189.4 PV only, 191.2 both at level 1; another: 193.4 PV only, 191.5 with S at level 1 and PV at level 2 (the default), 195.9 the other way round
 #endif
 #ifndef V3A_ATTN_PRIO_S_LEVEL
 #define V3A_ATTN_PRIO_S_LEVEL 1
 #endif
 #ifndef V3A_ATTN_PRIO_PV_LEVEL
-#define V3A_ATTN_PRIO_PV_LEVEL 1
+#define V3A_ATTN_PRIO_PV_LEVEL 2
 #endif
 #ifndef V3A_ATTN_PF
 #define V3A_ATTN_PF 2
