@@ -41,7 +41,7 @@
 #define V3A_ATTN_PRIO_PV_LEVEL 2
 #endif
 #ifndef V3A_ATTN_PF
-#define V3A_ATTN_PF 2
+#define V3A_ATTN_PF 3   // LDS fragment reads ahead of their MFMA (plain kernel): 189.6 / 186.4 / 184.9 / 192.6 us for 1 / 2 / 3 / 4 (4 spills)
 #endif
 #ifndef V3A_PW_ABL
 #define V3A_PW_ABL 0     // experiment builds only (tools/abl_build.sh)
