@@ -323,6 +323,7 @@ def attention(
     key_bias (D=128 only): fp32 [B, >=Nk], added to the scaled score of every query (log-multiplicity of merged keys).
     kv_seg (D=128 only): k / vt are the FIRST of Nk / kv_seg equally laid out segments k_seg_stride / vt_seg_stride elements apart
     (the per-rank slabs of an all-gather), read in place.
+    kv_period / kv_valid: key k takes part only if (k % kv_period) < kv_valid (padded per-view token layout); not together with a bias.
     kv_split > 1 (D=128 only): the keys of every query block are divided among kv_split workgroups whose partial softmaxes a second
     launch merges - for launches with too few query blocks to fill the chip; deterministic, not bit-identical to kv_split = 1."""
     ws = None
