@@ -282,6 +282,35 @@ def main():
         tail = {"points": M, "voxels": int(v["keys"].shape[0]), "voxelize+fuse_ms": round(vox_ms, 2), "gaussian_adapter_ms": round(ad_ms, 2),
                 "orbit_render_ms_132_cameras_448": round(rd_ms, 1)}
         del pts, raw, v, gs, gsp
+    # boxes of one pool differ by up to 5 % on identical binaries (profiles/r3/README.md): two fixed launches of the product library,
+    # untimed extras, so that lines from different boxes can be put side by side
+    box = None
+    if rank == 0:
+        gb = torch.Generator(device=dev).manual_seed(1)
+        Mb = 8192
+        xa, xw = torch.randn(Mb, 1536, device=dev, generator=gb).bfloat16(), (torch.randn(1536, 1536, device=dev, generator=gb) / 39.0).bfloat16()
+        qb_, kb_ = (torch.randn(Mb, 1536, device=dev, generator=gb) * 0.5).bfloat16(), (torch.randn(Mb, 1536, device=dev, generator=gb) * 0.5).bfloat16()
+        vtb, ob = torch.randn(1536, Mb, device=dev, generator=gb).bfloat16(), torch.empty(Mb, 1536, device=dev, dtype=torch.bfloat16)
+
+        def best_us(fn, n=20, rounds=4):
+            for _ in range(5):
+                fn()
+            bt = 1e9
+            for _ in range(rounds):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                bt = min(bt, e0.elapsed_time(e1) / n * 1e3)
+            return bt
+        g_us = best_us(lambda: ops.gemm(xa, xw, None, out=ob))
+        a_us = best_us(lambda: ops.attention(qb_, kb_, vtb, ob, B=2, H=12, Nq=4096, Nk=4096, D=128, q_batch_stride=4096 * 1536, k_batch_stride=4096 * 1536,
+                                            vt_batch_stride=4096, o_batch_stride=4096 * 1536))
+        box = {"gemm_8192x1536x1536_us": round(g_us, 1), "self_attention_2x12x4096_us": round(a_us, 1),
+               "note": "untimed extras: best of 4 x 20 back-to-back launches on seeded data; the same launches read 38-41 / 184-192 us across the boxes of round 3"}
+        del xa, xw, qb_, kb_, vtb, ob
     if rank == 0:
         ps = probe.summary()
         ach = ps["flops_per_launch"] / (ps["avg_ms"] * 1e-3) / 1e12 if ps["launches"] else 0.0
@@ -313,6 +342,7 @@ def main():
                                                "stitch+recon": round(stage.recon_ms, 1)},
                        "orbit_render_ms_132_cameras_448 (untimed extra)": round(render_ms, 1),
                        "recon_tail_on_spread_cloud (untimed extra)": tail,
+                       "box_speed_probe (untimed extra)": box,
                        "dit_model_tflops_per_s": round(2 * a.denoise_steps * fwd_flops / (stage.denoise_ms * 1e-3) / 1e12, 1),
                        "dit_executed_tflops_per_s": round(2 * a.denoise_steps * dit_flops_executed(N, cfg.dim, cfg.ffn_dim, cfg.num_layers, ctx_keys)
                                                           / (stage.denoise_ms * 1e-3) / 1e12, 1),
