@@ -130,6 +130,8 @@ class WanDiT:
         self._rope: Dict[tuple, torch.Tensor] = {}
         self._ctx: Dict[tuple, tuple] = {}  # (B, L, thread) -> (prompt key, persistent cross-attention K / V^T buffers)
         self.merge_padding_keys = True      # see _context
+        self.overlap_vt = False             # V^T GEMM on a second stream beside the q|k RMSNorm + RoPE pass (forward)
+        self._side = None
         # "fp8": self-attention on the block-scaled fp8 MFMA (BASELINE config #4; csrc/attention_fp8.hip): q / k (after RMSNorm + RoPE)
         # and V^T are rounded to e4m3 with the unit scales below.  "bf16" (default) is the reference's precision.
         self.attn_dtype = "bf16"
@@ -348,6 +350,7 @@ class WanDiT:
         for li in range(nl):
             b, m = self.blocks[li], mod[li]
             # --- self attention
+            vt_done = None
             norm(scale=m[:, 1], shift=m[:, 0], rows_per_batch=Nl)
             if P == 1:
                 lin(ws.n, b, "wqk", b["bqk"], out=ws.qk)
@@ -357,7 +360,21 @@ class WanDiT:
                         ops.gemm(b["wv8"], ws.a8[r0:r1], b["bv"], out=ws.vt if vbs == N else ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True,
                                  a_scale=b["swv"], w_scale=ws.sa[r0:r1])
                 elif vbs == N:  # no per-item padding: V^T of the whole batch is one [d, B*N] GEMM (256 tiles of 192x256 at 1.3B)
-                    ops.gemm(b["wv"], ws.n, b["bv"], out=ws.vt, bias_row=True)
+                    if self.overlap_vt and self.attn_dtype != "fp8":
+                        # V^T on a second stream, ordered behind the q|k GEMM: it then runs beside the HBM-bound RMSNorm + RoPE pass over
+                        # q|k (whose waves fit next to the GEMM's on a CU) instead of in front of it
+                        main = torch.cuda.current_stream()
+                        if self._side is None:
+                            self._side = torch.cuda.Stream(device=self.device)
+                        e_qk = torch.cuda.Event()
+                        e_qk.record(main)
+                        self._side.wait_event(e_qk)
+                        with torch.cuda.stream(self._side):
+                            ops.gemm(b["wv"], ws.n, b["bv"], out=ws.vt, bias_row=True)
+                            vt_done = torch.cuda.Event()
+                            vt_done.record(self._side)
+                    else:
+                        ops.gemm(b["wv"], ws.n, b["bv"], out=ws.vt, bias_row=True)
                 else:
                     for bi in range(B):
                         ops.gemm(b["wv"], ws.n[bi * N:(bi + 1) * N], b["bv"], out=ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True)
@@ -378,6 +395,8 @@ class WanDiT:
                                       k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d, q_scale=qs, k_scale=ksc, v_scale=vs)
                 else:
                     ops.rmsnorm_rope(ws.qk, b["nq"], out=ws.qk, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps, weight2=b["nk"])
+                    if vt_done is not None:
+                        torch.cuda.current_stream().wait_event(vt_done)
                     ops.attention(q, k, ws.vt, ws.ao, B=B, H=H, Nq=N, Nk=N, D=hd, q_batch_stride=N * 2 * d,
                                   k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d)
             else:
