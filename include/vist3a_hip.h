@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 16) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 17) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -166,10 +166,6 @@ typedef struct {
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 size_t v3a_attention_split_workspace_bytes(int B, int H, int Nq, int D, int kv_split);
-/* Experiment switch for the hd = 128 unbiased, unmasked launch (the DiT self-attention): 0 / 1 = the production kernel (128-query
- * workgroups, three per CU); 2 / 3 = the one-wave-per-SIMD study kernels, which exist only in builds with -DV3A_ATTN_EXPERIMENTAL
- * (tools/abl_build.sh) and are ignored otherwise.  Process-wide; returns the previous value. */
-int v3a_attention_set_kernel(int which);
 
 /* ------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) flash attention forward on the block-scaled MFMA (K = 64, twice the bf16 rate): the self-attention launch of

@@ -193,13 +193,21 @@ def test_merge_lora_matches_reference_eval_merge_golden():
     import pytest
     with pytest.raises(KeyError):
         merge_lora({k: v.clone() for k, v in base.items()}, {**lora, "blocks.0.qkv.bias": torch.zeros(5)}, 16.0, 4)
-    # ... while adapters of layers that are not part of the engine at all (the reference wraps every Linear / Conv2d and loads with
-    # strict=False: dropped DINO blocks, unused heads) are skipped with ONE warning and leave the result unchanged
+    # ... adapters of layers that are not part of the model at all raise as well (a stray `module.` / `stitched_3d_model.` prefix, a
+    # renamed block: merging nothing and reconstructing with un-adapted weights would have no other symptom) ...
+    extra = {"blocks.7.qkv.bias": torch.zeros(36), "blocks.7.qkv.lora_A": torch.zeros(4, 12), "blocks.7.qkv.lora_B": torch.zeros(36, 4)}
+    with pytest.raises(KeyError):
+        merge_lora({k: v.clone() for k, v in base.items()}, {**lora, **extra}, float(meta["alpha"]), int(meta["r"]))
+    with pytest.raises(KeyError):
+        merge_lora({k: v.clone() for k, v in base.items()}, {"module." + k: v for k, v in lora.items()}, float(meta["alpha"]), int(meta["r"]))
+    # ... except under the explicit list of modules the reference wraps but the inference forward never runs (one warning)
     sd2 = {k: v.clone() for k, v in base.items()}
+    unused = {"encoder.point_head." + k: v for k, v in extra.items()}
     with pytest.warns(UserWarning, match="skipped 3 adapter tensors"):
-        n2 = merge_lora(sd2, {**lora, "blocks.7.qkv.bias": torch.zeros(36), "blocks.7.qkv.lora_A": torch.zeros(4, 12),
-                              "blocks.7.qkv.lora_B": torch.zeros(36, 4)}, float(meta["alpha"]), int(meta["r"]))
+        n2 = merge_lora(sd2, {**lora, **unused}, float(meta["alpha"]), int(meta["r"]))
     assert n2 == 6 and all(torch.equal(sd2[k], sd[k]) for k in sd)
+    with pytest.raises(KeyError), pytest.warns(UserWarning):    # adapter matrices present, none merged
+        merge_lora({k: v.clone() for k, v in base.items()}, unused, 16.0, 4)
 
 
 def test_parse_lora_mode_matches_reference_parser_golden():

@@ -217,3 +217,32 @@ def test_engine_conf_mask_branch_matches_reference_golden(hip_lib):
     mask = (dc > out["conf_valid"].cpu())
     agree = (mask == g["mask"].bool()).float().mean().item()
     assert agree > 0.97, agree
+
+
+def test_boundary_conf_valid_mask_matches_reference_golden(hip_lib):
+    """EncoderOutput.depth_dict["conf_valid_mask"] (anysplat_stitched.py:381-387, returned at :494): depth_conf > quantile under
+    render_conf (with or without the voxel branch), all-true otherwise - against the mask the reference itself produced."""
+    from safetensors.torch import load_file
+    from pathlib import Path
+    from vist3a_amd.models.anysplat_stitched import AnySplatStitched, AnySplatWeights
+    from vist3a_amd.recon.engine import ReconCfg
+    g = load_file(str(Path(__file__).parent / "golden" / "recon_tiny_conf.safetensors"))
+    kw = dict(C=64, heads=1, n_dino=22, depth=24, cam_heads=2, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+    sd = R.make_recon_weights(R.ReconCfg(**kw), seed=41)
+    m = AnySplatStitched(AnySplatWeights(dict(sd), ReconCfg(**kw, voxelize=False, render_conf=True, conf_threshold=0.1)), "enc_blocks_2", "cuda")
+    ref_mask = g["mask"].bool()
+    out = m(g["latent"].cuda(), g["image"].cuda(), train=False)
+    mask = out.depth_dict["conf_valid_mask"]
+    assert mask.dtype == torch.bool and mask.shape == ref_mask.shape
+    assert int(mask.sum()) == out.gaussians.means.shape[1]            # the mask IS the compaction the Gaussians went through
+    assert abs(int(mask.sum()) - int(ref_mask.sum())) <= 1
+    agree = (mask.cpu() == ref_mask).float().mean().item()
+    assert agree > 0.97, agree                                        # bf16 noise moves confidences across the threshold
+    # render_conf with the voxel branch: the mask is still the quantile mask (the reference computes it before branching)
+    m.encoder.cfg.voxelize = True
+    out_v = m(g["latent"].cuda(), g["image"].cuda(), train=False)
+    assert torch.equal(out_v.depth_dict["conf_valid_mask"], mask)
+    # without render_conf: all-true
+    m.encoder.cfg.render_conf = False
+    out_n = m(g["latent"].cuda(), g["image"].cuda(), train=False)
+    assert bool(out_n.depth_dict["conf_valid_mask"].all()) and out_n.depth_dict["conf_valid_mask"].shape == ref_mask.shape

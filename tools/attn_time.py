@@ -3,8 +3,7 @@
   V3A_LIB=<other build>                                   A/B against another library build in a second process (vist3a_amd/lib.py)
   V3A_ATTN_SAVE=/tmp/prefix                               first process saves the output, later ones compare bit-for-bit with it and
                                                           print, for differing rows, which build is closer to an fp64 softmax
-  V3A_ATTN_D=64  V3A_ATTN_PERIOD=1032,1029                the reconstruction's head dim / padded view layout (kv_period, kv_valid)
-  V3A_ATTN_STUDY=1                                        also run the one-wave-per-SIMD study kernels 2 / 3 (-DV3A_ATTN_EXPERIMENTAL builds)"""
+  V3A_ATTN_D=64  V3A_ATTN_PERIOD=1032,1029                the reconstruction's head dim / padded view layout (kv_period, kv_valid)"""
 import sys, json, os
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -23,8 +22,7 @@ for B, H, N in shapes:
     for b in range(B):
         vt[:, b * N:(b + 1) * N] = v[b * N:(b + 1) * N].t()
     outs = {}
-    for which in ((1, 2, 3) if os.environ.get("V3A_ATTN_STUDY") else (1,)):
-        L.v3a_attention_set_kernel(which)
+    for which in (1,):
         o = torch.empty(B * N, d, device="cuda", dtype=torch.bfloat16)
         per = [int(x) for x in os.environ.get("V3A_ATTN_PERIOD", "0,0").split(",")]   # kv_period,kv_valid (the reconstruction's padded view layout)
         nk = int(os.environ.get("V3A_ATTN_NK", N))   # cross-attention: fewer keys than queries, with a per-key bias (the merged padding key)
@@ -65,7 +63,3 @@ for B, H, N in shapes:
             else:
                 torch.save(o.cpu(), f)
         print(json.dumps(dict(B=B, H=H, N=N, kernel=which, us=round(us, 1), rounds_us=times, tflops=round(4 * B * H * N * N * D / us / 1e6), rel=rel)), flush=True)
-    L.v3a_attention_set_kernel(0)
-    if 2 in outs:
-        print(json.dumps(dict(B=B, H=H, N=N, bit_identical_2=bool(torch.equal(outs[1], outs[2])), bit_identical_3=bool(torch.equal(outs[1], outs[3])),
-                              max_abs_diff_3=(outs[1].float() - outs[3].float()).abs().max().item())), flush=True)

@@ -43,9 +43,6 @@
 #ifndef V3A_ATTN_PF
 #define V3A_ATTN_PF 3   // LDS fragment reads ahead of their MFMA (plain kernel): 189.6 / 186.4 / 184.9 / 192.6 us for 1 / 2 / 3 / 4 (4 spills)
 #endif
-#ifndef V3A_PW_ABL
-#define V3A_PW_ABL 0     // experiment builds only (tools/abl_build.sh)
-#endif
 
 namespace {
 
@@ -553,12 +550,13 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_plain_kernel(const AttnP 
         // the tile: v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second, so two copies of mx
         // become [lo, lo] and [hi, hi].  As an asm statement: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) dropped the second
         // result - max(r0, r0) in the disassembly, i.e. a reference that ignores the upper half (tools/probe/permlane_probe.hip shows the
-        // instruction itself is fine).  s_nop 1: VALU write -> permlane read.
+        // instruction itself is fine).  s_nop 1 on both sides: VALU write -> permlane read, and permlane write -> the consuming v_max
+        // (an asm statement is invisible to hipcc's hazard recogniser, so the wait states are spelled out; cost: not measurable).
 #ifdef V3A_ATTN_BPERM
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 #else
       float ma = mx, mb = mx;
-      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ma), "+v"(mb));
       mx = fmaxf(ma, mb);
 #endif
     }
@@ -686,668 +684,6 @@ __global__ __launch_bounds__(NW * 64, 3) void attn_fwd_plain_kernel(const AttnP 
   }
 }
 
-// ==============================================================================================================================
-// EXPERIMENTAL (compiled only with -DV3A_ATTN_EXPERIMENTAL; tools/abl_build.sh builds it): round-3 study of the one-wave-per-SIMD,
-// 64-queries-per-wave structure for the DiT self-attention.  NOT used by the product; kept because the measurements below decide
-// what the next attempt has to look like ("round 3"):
-//   attn_fwd64_kernel  (kernel 2): S -> softmax -> PV in sequence.  Bit-identical to the ROUND-2 production kernel, deterministic (the
-//                      round-3 production loop computes all 32 exponent arguments of a tile as fused multiply-adds where hipcc had left one
-//                      of them as a packed multiply + subtract: 88 of 25 M outputs of the DiT launch move by one bf16 ulp).
-//                      B=2 H=16 N=4096 (two full rounds of 256-query workgroups): 270 us vs 280 us; the DiT's H=12 (1.5 rounds): 266 vs 203.
-//   attn_fwd64p_kernel (kernel 3): software-pipelined (S^T double-buffered in registers, finish-softmax(t) beside the S MFMAs of t+1,
-//                      start-softmax(t+1) beside the PV MFMAs of t).  251-258 us at H=16.  With the row-max exchange through
-//                      ds_bpermute and MFMA fences at the phase ends it is bit-identical on small grids; at 512 workgroups the
-//                      single-MFMA-slot form still shows run-to-run differences (an unresolved register hazard) - do not ship.
-// What the stamps (s_memtime per phase) showed: a lone wave issues in order, ~5.4 cycles per instruction; VALU work overlaps an MFMA
-// only when it sits directly behind it (four MFMAs followed by twenty VALU instructions cost 128 + 20 x 5 cycles); the softmax of 64
-// queries is ~430 instructions per 64 MFMAs, so even the perfectly interleaved stream is issue-bound at ~45 cycles per MFMA.
-// ==============================================================================================================================
-#ifdef V3A_ATTN_EXPERIMENTAL
-// ------------------------------------------------------------------------------------------------------------------------------
-// Round 3: the DiT self-attention (hd = 128, no bias / mask) with ONE wave per SIMD and 64 queries per wave.
-//   * a workgroup = 4 waves = 256 queries; every K / V^T tile in LDS serves 256 queries (half the LDS-DMA pieces per query of the
-//     128-query kernel above) and every fragment read from LDS feeds two MFMAs (two 32-query blocks A and B per wave);
-//   * register files are assigned by hand through inline-asm operand classes, because hipcc left to itself shuttles MFMA results
-//     between the two files (measured on the QB = 2 instantiation of the kernel above: ~480 v_accvgpr moves per 64 MFMAs):
-//       O^T accumulators (128 registers) and the Q fragments (64) live in the ACCUMULATOR file for the whole kernel,
-//       S^T (64), P (32), the K / V^T fragments in flight and the softmax temporaries in the architectural VGPRs;
-//   * MFMAs are asm statements, so hipcc neither pads their result hazards nor moves them: the `mfma_fence` statements below carry the
-//     wait states an MFMA result needs before a VALU instruction may read it (8-pass XDL op: 12 states; two s_nop 15 are issued).
-// Same arithmetic per query row as attn_fwd_kernel (same ascending-k MFMA chains, same per-32-row rescale decision): bit-identical.
-__device__ __forceinline__ void mfma_s0(f32x16& d, const bf16x8& a, const bf16x8& b) {   // d = a . b          (S^T, first k step)
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
-}
-__device__ __forceinline__ void mfma_s(f32x16& d, const bf16x8& a, const bf16x8& b) {    // d += a . b         (S^T in VGPRs, Q in AGPRs)
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
-}
-__device__ __forceinline__ void mfma_o(f32x16& d, const bf16x8& a, const bf16x8& b) {    // d += a . b         (O^T in AGPRs)
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
-}
-// LDS-DMA that hipcc does not see: behind the builtin it orders the next LDS read after the copy (s_waitcnt vmcnt(0) straight after
-// the issue - with one wave per SIMD that puts the whole L2 latency of every tile on the critical path).  Here the copy is counted by
-// the explicit s_waitcnt vmcnt at the end of the tile.  M0 = wave-uniform LDS byte address of the 1 KB piece (lane i lands at +16 i).
-__device__ __forceinline__ void glds16_raw(const void* gsrc, unsigned lds_byte_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
-}
-__device__ __forceinline__ void mfma_fence_v(f32x16& a, f32x16& b) {   // MFMA results in VGPRs -> VALU readers
-  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void mfma_fence_a(f32x16& a, f32x16& b, f32x16& c, f32x16& d) {   // MFMA results in AGPRs -> v_accvgpr_read
-  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a), "+a"(b), "+a"(c), "+a"(d));
-}
-
-// online softmax of one 32-query block over one 64-key tile: S^T (two 32-key sub-tiles) -> P fragments; returns the rescale factor
-// (1 when the exponent reference did not move).  Identical to the in-line code of attn_fwd_kernel.
-__device__ __forceinline__ bool softmax_block(const f32x16& s0, const f32x16& s1, float c, float& m_run, float& l_run, bf16x8 (&pf)[4],
-                                              float& alpha) {
-  constexpr float DEFER = 8.0f;
-  float mx = s0[0];
-#pragma unroll
-  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const float m_new = fmaxf(m_run, mx);
-  const bool rescale = __builtin_amdgcn_ballot_w64((m_new - m_run) * c > DEFER) != 0;
-  alpha = 1.0f;
-  if (rescale) {
-    alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    m_run = m_new;
-  }
-  const float mc = m_run * c;
-  float psum = 0.f;
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    float pv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pv[r] = __builtin_amdgcn_exp2f((t ? s1[r] : s0[r]) * c - mc);
-      psum += pv[r];
-    }
-#pragma unroll
-    for (int ks2 = 0; ks2 < 2; ++ks2) {
-      u32x4 pk;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {   // a VECTOR fptrunc: selected as one v_cvt_pk_bf16_f32 (two scalar casts became 2 x cvt + v_perm here)
-        const f32x2 pr = {pv[8 * ks2 + 2 * e], pv[8 * ks2 + 2 * e + 1]};
-        pk[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(pr, v3a_bf16x2));
-      }
-      pf[2 * t + ks2] = __builtin_bit_cast(bf16x8, pk);
-    }
-  }
-  l_run = l_run * alpha + psum;
-  return rescale;
-}
-
-__global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const AttnP p) {
-  constexpr int D = 128, NW = 4, KV = 64, KROWB = 256, KTILE = KV * KROWB, VTILE = D * 128, STAGE = KTILE + VTILE;
-  constexpr int KINS = KTILE / 1024 / NW, VINS = VTILE / 1024 / NW, KS = 8, DT = 4, OPITCH = D * 2 + 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int nqb = (p.Nq + 255) / 256;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = bid / nqb, qb = bid % nqb;
-  const int b = bh / p.H, h = bh % p.H;
-  const int q0 = qb * 256 + wave * 64;
-  const char* Qb = p.q + ((size_t)b * p.q_bs + (size_t)h * D) * 2;
-  const char* Kb = p.k + ((size_t)b * p.k_bs + (size_t)h * D) * 2;
-  const char* Vb = p.vt + ((size_t)h * D * p.ldvt + (size_t)b * p.vt_bs) * 2;
-
-  bf16x8 qf[2][KS];
-#pragma unroll
-  for (int qq = 0; qq < 2; ++qq) {
-    int qr = q0 + qq * 32 + l31;
-    qr = qr < p.Nq ? qr : p.Nq - 1;
-    const char* qp = Qb + (size_t)qr * p.ldq * 2 + hi * 16;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[qq][ks] = *(const bf16x8*)(qp + ks * 32);
-  }
-  // DMA sources (same LDS image and swizzles as attn_fwd_kernel at hd = 128)
-  const char* kp[KINS];
-  const char* vp[VINS];
-#pragma unroll
-  for (int j = 0; j < KINS; ++j) {
-    const int r = (j * NW + wave) * 4 + lane / 16, cch = lane % 16;
-    kp[j] = Kb + (size_t)r * p.ldk * 2 + (size_t)(cch ^ (r & 15)) * 16;
-  }
-#pragma unroll
-  for (int j = 0; j < VINS; ++j) {
-    const int r = (j * NW + wave) * 8 + (lane >> 3);
-    const int cch = (lane & 7) ^ ((r >> 1) & 7);
-    vp[j] = Vb + ((size_t)r * p.ldvt + cch * 8) * 2;
-  }
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(LDS_AS char*)smem);
-  auto stage = [&](int s, int kt) {
-    const unsigned sb = lds0 + s * STAGE + wave * 1024;
-#pragma unroll
-    for (int j = 0; j < KINS; ++j) glds16_raw(kp[j] + (size_t)kt * KV * p.ldk * 2, sb + j * NW * 1024);
-#pragma unroll
-    for (int j = 0; j < VINS; ++j) glds16_raw(vp[j] + (size_t)kt * KV * 2, sb + KTILE + j * NW * 1024);
-  };
-  const int pi = (l31 & 3) + 4 * (l31 >> 3) + 16 * ((l31 >> 2) & 1);
-  int kfo[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kfo[ks] = pi * KROWB + (((2 * ks + hi) ^ (pi & 15)) << 4);
-  int vfo[4];
-#pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) vfo[c4] = l31 * 128 + (((4 * (c4 >> 1) + 2 * hi + (c4 & 1)) ^ ((l31 >> 1) & 7)) << 4);
-
-  f32x16 oa[DT], ob[DT];    // O^T of q-block A / B
-#pragma unroll
-  for (int i = 0; i < DT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oa[i][r] = 0.f; ob[i][r] = 0.f; }
-  float ma = -1e30f, mb = -1e30f, la = 0.f, lb = 0.f;
-  const float c = p.scale_log2e;
-  const int nkt = p.Nk / KV;
-
-  stage(0, 0);
-  // a wait hipcc SEES (the builtin, not an asm string): it retires the Q loads in the compiler's own bookkeeping - otherwise every
-  // first use of a Q register inside the loop gets a compiler-inserted s_waitcnt vmcnt(7..0) that drains the hidden LDS-DMA stream
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_s_barrier();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-    const char* sK = smem + cur * STAGE;
-    const char* sV = sK + KTILE;
-    f32x16 sa0, sa1, sb0, sb1;
-    {   // S^T = K . Q^T: 16 K fragments (2 sub-tiles x 8 k steps), each feeding both q-blocks; fragment reads run two ahead of their MFMAs
-        // (the MFMA statements are volatile asm: hipcc does not move LDS reads across them, so the distance is set here)
-      bf16x8 kf[16];
-      auto ldk = [&](int i) { return *(const bf16x8*)(sK + (i & 1) * 32 * KROWB + kfo[i >> 1]); };   // i = 2 ks + sub-tile
-#pragma unroll
-      for (int i = 0; i < 4; ++i) kf[i] = ldk(i);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {   // four accumulators in rotation (a dependent MFMA two slots behind its producer stalls)
-        if (ks + 2 < KS) { kf[2 * ks + 4] = ldk(2 * ks + 4); kf[2 * ks + 5] = ldk(2 * ks + 5); }
-        if (ks == 0) { mfma_s0(sa0, kf[0], qf[0][0]); mfma_s0(sb0, kf[0], qf[1][0]); mfma_s0(sa1, kf[1], qf[0][0]); mfma_s0(sb1, kf[1], qf[1][0]); }
-        else {
-          mfma_s(sa0, kf[2 * ks], qf[0][ks]); mfma_s(sb0, kf[2 * ks], qf[1][ks]);
-          mfma_s(sa1, kf[2 * ks + 1], qf[0][ks]); mfma_s(sb1, kf[2 * ks + 1], qf[1][ks]);
-        }
-      }
-    }
-    mfma_fence_v(sa0, sa1);
-    mfma_fence_v(sb0, sb1);
-    bf16x8 pa[4], pb[4];
-    float al;
-    if (softmax_block(sa0, sa1, c, ma, la, pa, al)) {
-      mfma_fence_a(oa[0], oa[1], oa[2], oa[3]);
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oa[i][r] *= al;
-    }
-    if (softmax_block(sb0, sb1, c, mb, lb, pb, al)) {
-      mfma_fence_a(ob[0], ob[1], ob[2], ob[3]);
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ob[i][r] *= al;
-    }
-    {   // O^T += V^T . P^T: 16 V^T fragments (4 key chunks x 4 d tiles), each feeding both q-blocks, reads two ahead
-      bf16x8 vf[16];
-      auto ldv = [&](int j) { return *(const bf16x8*)(sV + (j & 3) * 4096 + vfo[j >> 2]); };
-      vf[0] = ldv(0);
-      vf[1] = ldv(1);
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (j + 2 < 16) vf[j + 2] = ldv(j + 2);
-        if ((j & 3) == 0) asm volatile("s_nop 1" : "+v"(pa[j >> 2]), "+v"(pb[j >> 2]));   // VALU-written P -> MFMA operand
-        mfma_o(oa[j & 3], vf[j], pa[j >> 2]);
-        mfma_o(ob[j & 3], vf[j], pb[j >> 2]);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  mfma_fence_a(oa[0], oa[1], oa[2], oa[3]);
-  mfma_fence_a(ob[0], ob[1], ob[2], ob[3]);
-  char* reg = smem + wave * (32 * OPITCH);
-  char* Ob = p.o + ((size_t)b * p.o_bs + (size_t)h * D) * 2;
-#pragma unroll
-  for (int qq = 0; qq < 2; ++qq) {
-    const float lx = qq ? lb : la;
-    const float inv = 1.0f / (lx + __shfl_xor(lx, 32, 64));
-#pragma unroll
-    for (int i = 0; i < DT; ++i) {
-      const f32x16& o = qq ? ob[i] : oa[i];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 pk;
-        pk[0] = pack_bf16x2(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
-        pk[1] = pack_bf16x2(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
-        *(u32x2*)(reg + l31 * OPITCH + (i * 32 + g * 8 + hi * 4) * 2) = pk;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int idx = it * 64 + lane;
-      const int ql = idx / 16, ch = idx % 16;
-      const u32x2 lo = *(const u32x2*)(reg + ql * OPITCH + ch * 16);
-      const u32x2 hi2 = *(const u32x2*)(reg + ql * OPITCH + ch * 16 + 8);
-      const int qr = q0 + qq * 32 + ql;
-      if (qr < p.Nq) {
-        u32x4 v;
-        v[0] = lo[0]; v[1] = lo[1]; v[2] = hi2[0]; v[3] = hi2[1];
-        *(u32x4*)(Ob + ((size_t)qr * p.ldo) * 2 + ch * 16) = v;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ---- the software-pipelined form of attn_fwd64_kernel ---------------------------------------------------------------------------------
-// With ONE wave per SIMD nothing else fills the matrix pipe while the wave runs its softmax (measured on the kernel above: 4400 cycles per
-// 64-key tile for 2048 cycles of MFMAs - a lone wave issues one instruction per ~4 cycles, and the softmax of 64 queries is ~430 of them).
-// Here the instruction stream itself interleaves the two: every pair of MFMAs is followed by its share of VALU work that belongs to a
-// DIFFERENT tile (S^T is double-buffered in registers),
-//   phase A (32 MFMAs):  S^T(t+1) = K(t+1) . Q^T        beside  finish-softmax(t): p = 2^x, row sums, bf16 packing  -> P(t)
-//   phase B (32 MFMAs):  O^T     += V^T(t) . P(t)^T     beside  start-softmax(t+1): row max, rescale decision, x = s c - m c (in place)
-// pinned by __builtin_amdgcn_sched_barrier(0) between the steps.  A rescale decided in phase B of tile t is applied to O right before the
-// PV MFMAs of tile t+1 and to l in its finish-softmax.  Arithmetic per query row is unchanged (bit-identical to both kernels above).
-struct SSet { f32x16 a0, a1, b0, b1; };   // S^T of q-block A / B, key sub-tiles 0 / 1 (after start-softmax: x = s c - m c)
-
-__device__ __forceinline__ float max8(float m, const f32x16& s, int r0) {
-#pragma unroll
-  for (int r = 0; r < 8; ++r) m = fmaxf(m, s[r0 + r]);
-  return m;
-}
-__device__ __forceinline__ float half_swap_max(float mx) {   // max over the two lane halves (the two 16-key halves of a query's row)
-  // (v_permlane32_swap on two copies of mx would avoid the LDS round trip, but measured NOT equivalent here: ~40 % of the rows got a
-  //  reference below their maximum - kept behind the experiment switch until understood)
-  if constexpr (!(V3A_PW_ABL & 4)) return fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const unsigned u = __builtin_bit_cast(unsigned, mx);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
-}
-// rescale decision of one q-block (same rule as attn_fwd_kernel): returns whether the wave moves its exponent reference
-__device__ __forceinline__ bool softmax_decide(float mx, float c, float& m_run, float& alpha) {
-  constexpr float DEFER = 8.0f;
-  const float m_new = fmaxf(m_run, mx);
-  const bool rescale = __builtin_amdgcn_ballot_w64((m_new - m_run) * c > DEFER) != 0;
-  alpha = 1.0f;
-  if (rescale) {
-    alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    m_run = m_new;
-  }
-  return rescale;
-}
-__device__ __forceinline__ void fma8(f32x16& s, int r0, float c, float mc) {
-  // asm: left to itself hipcc SLP-packs these into v_pk_fma_f32, which is slower than two v_fma_f32 beside MFMAs (MI355X_MICROARCH.md)
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    float x = s[r0 + r];
-    asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(x) : "v"(x), "v"(c), "v"(mc));
-    s[r0 + r] = x;
-  }
-}
-// finish-softmax of four values: p = 2^x, psum += p (in order), two packed bf16 words
-__device__ __forceinline__ void exp4(const f32x16& x, int r0, float& psum, unsigned& w0, unsigned& w1) {
-  float pv[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    pv[r] = (V3A_PW_ABL & 2) ? x[r0 + r] : __builtin_amdgcn_exp2f(x[r0 + r]);
-    psum += pv[r];
-  }
-  const f32x2 p0 = {pv[0], pv[1]}, p1 = {pv[2], pv[3]};
-  w0 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p0, v3a_bf16x2));
-  w1 = __builtin_bit_cast(unsigned int, __builtin_convertvector(p1, v3a_bf16x2));
-}
-
-// Value anchors: an empty volatile asm that "modifies" the values.  The MFMAs are volatile asm statements, which keep their order, so a
-// computation whose result passes through an anchor cannot be SUNK by the IR optimiser below the MFMAs that follow the anchor (it sinks
-// the finish-softmax to its first use otherwise: all 64 exponentials end up in one block in front of the PV MFMAs).
-#define PIN1(a) asm volatile("" : "+v"(a))
-#define PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
-#define PIN3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
-// O <- O alpha for one accumulator tile living in the accumulator file, through 16 temporaries at a time (the cold rescale path must not
-// raise the register pressure of the loop: with all 128 values in flight hipcc spilled loop-invariant addresses to scratch)
-__device__ __forceinline__ void scale_acc(f32x16& o, float alpha) {
-  f32x16 t = o;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] *= alpha;
-  asm volatile("" : "+v"(t));
-  o = t;
-  asm volatile("s_nop 1" : "+a"(o));
-}
-
-#if V3A_PW_ABL & 32
-__device__ long long g_pw_dbg[64];   // experiment builds: s_memtime stamps of one tile of block 0 / wave 0
-extern "C" int v3a_debug_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pw_dbg), n * 8); }
-#define STAMP(i) do { if (blockIdx.x == 0 && tid == 0 && kt == 20) g_pw_dbg[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-
-__device__ __forceinline__ void pw_fence_s(SSet& n) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(n.a0), "+v"(n.a1), "+v"(n.b0), "+v"(n.b1)); }
-__device__ __forceinline__ void pw_fence_o(f32x16 (&a)[4], f32x16 (&b)[4]) {
-  asm volatile("s_nop 15\n\ts_nop 3" : "+a"(a[0]), "+a"(a[1]), "+a"(a[2]), "+a"(a[3]), "+a"(b[0]), "+a"(b[1]), "+a"(b[2]), "+a"(b[3]));
-}
-
-// finish-softmax of two values: p = 2^x, psum += p (in order), one packed bf16 word
-__device__ __forceinline__ unsigned exp2w(const f32x16& x, int r0, float& psum) {
-  const float p0 = __builtin_amdgcn_exp2f(x[r0]), p1 = __builtin_amdgcn_exp2f(x[r0 + 1]);
-  psum += p0;
-  psum += p1;
-  const f32x2 pr = {p0, p1};
-  return __builtin_bit_cast(unsigned int, __builtin_convertvector(pr, v3a_bf16x2));
-}
-
-__global__ __launch_bounds__(256, 1) void attn_fwd64p_kernel(const AttnP p) {
-  constexpr int D = 128, NW = 4, KV = 64, KROWB = 256, KTILE = KV * KROWB, VTILE = D * 128, STAGE = KTILE + VTILE;
-  constexpr int KINS = KTILE / 1024 / NW, VINS = VTILE / 1024 / NW, KS = 8, DT = 4, OPITCH = D * 2 + 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
-  const int nqb = (p.Nq + 255) / 256;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = bid / nqb, qb = bid % nqb;
-  const int b = bh / p.H, h = bh % p.H;
-  const int q0 = qb * 256 + wave * 64;
-  const char* Qb = p.q + ((size_t)b * p.q_bs + (size_t)h * D) * 2;
-  const char* Kb = p.k + ((size_t)b * p.k_bs + (size_t)h * D) * 2;
-  const char* Vb = p.vt + ((size_t)h * D * p.ldvt + (size_t)b * p.vt_bs) * 2;
-
-  bf16x8 qf[2][KS];
-#pragma unroll
-  for (int qq = 0; qq < 2; ++qq) {
-    int qr = q0 + qq * 32 + l31;
-    qr = qr < p.Nq ? qr : p.Nq - 1;
-    const char* qp = Qb + (size_t)qr * p.ldq * 2 + hi * 16;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[qq][ks] = *(const bf16x8*)(qp + ks * 32);
-  }
-  // DMA sources: piece j of a tile = rows (j NW + wave) 4 .. + 3 (K) / (j NW + wave) 8 .. + 7 (V^T); the swizzle term does not depend on j
-  // (16 j and 32 j rows further on), so ONE per-lane pointer per operand and wave-uniform piece offsets do
-  const char* kp0;
-  const char* vp0;
-  {
-    const int r = wave * 4 + lane / 16, cch = lane % 16;
-    kp0 = Kb + (size_t)r * p.ldk * 2 + (size_t)(cch ^ (r & 15)) * 16;
-    const int rv = wave * 8 + (lane >> 3);
-    vp0 = Vb + ((size_t)rv * p.ldvt + ((lane & 7) ^ ((rv >> 1) & 7)) * 8) * 2;
-  }
-  // LDS: K tile t in stage t & 1 at offset 0, V^T tile t in stage t & 1 at offset KTILE
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(LDS_AS char*)smem) + wave * 1024;
-  const size_t kstep = (size_t)KV * p.ldk * 2, kpiece = (size_t)16 * p.ldk * 2, vpiece = (size_t)32 * p.ldvt * 2;
-  const int last = p.Nk / KV - 1;
-  // (tile indices past the end are clamped: the copy lands in a stage nobody reads any more - keeps the tile body branch-free)
-  auto dma_k = [&](int j, int kt) {
-    if constexpr (V3A_PW_ABL & 1) { if (kt > 1) return; }
-    glds16_raw(kp0 + (size_t)min(kt, last) * kstep + j * kpiece, lds0 + (kt & 1) * STAGE + j * NW * 1024);
-  };
-  auto dma_v = [&](int j, int kt) {
-    if constexpr (V3A_PW_ABL & 1) { if (kt > 1) return; }
-    glds16_raw(vp0 + (size_t)min(kt, last) * KV * 2 + j * vpiece, lds0 + (kt & 1) * STAGE + KTILE + j * NW * 1024);
-  };
-
-  const int pi = (l31 & 3) + 4 * (l31 >> 3) + 16 * ((l31 >> 2) & 1);
-  int kfo[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kfo[ks] = pi * KROWB + (((2 * ks + hi) ^ (pi & 15)) << 4);
-  int vfo[4];
-#pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) vfo[c4] = l31 * 128 + (((4 * (c4 >> 1) + 2 * hi + (c4 & 1)) ^ ((l31 >> 1) & 7)) << 4);
-
-  f32x16 oa[DT], ob[DT];
-#pragma unroll
-  for (int i = 0; i < DT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oa[i][r] = 0.f; ob[i][r] = 0.f; }
-  float ma = -1e30f, mb = -1e30f, la = 0.f, lb = 0.f;
-  float al_a = 1.f, al_b = 1.f;      // rescale factors decided by the last start-softmax, pending for O and l
-  bool rs_a = false, rs_b = false;
-  const float c = p.scale_log2e;
-  const int nkt = p.Nk / KV;
-  u32x4 pa[4], pb[4];                // P(t) fragments (bf16 pairs) of q-block A / B
-
-  auto ldk = [&](const char* sK, int j) {
-    if constexpr (V3A_PW_ABL & 8) { bf16x8 z = {1, 2, 3, 4, 5, 6, 7, (short)j}; asm volatile("" : "+v"(z)); return z; }
-    return *(const bf16x8*)(sK + (j >> 3) * 32 * KROWB + kfo[j & 7]);
-  };
-  auto ldv = [&](const char* sV, int j) {
-    if constexpr (V3A_PW_ABL & 8) { bf16x8 z = {1, 2, 3, 4, 5, 6, 7, (short)j}; asm volatile("" : "+v"(z)); return z; }
-    return *(const bf16x8*)(sV + (j & 3) * 4096 + vfo[j >> 2]);
-  };
-  // one S^T step = k step ks of BOTH key sub-tiles on both q-blocks: four MFMAs on four different accumulators.  A dependent MFMA
-  // is only cheap straight behind its producer or >= 4 MFMAs later: with two accumulators in rotation (a0 b0 a0 b0 ..) every MFMA waited
-  // for the write-back of the one before last - measured 60 cycles per MFMA with nothing else in the loop.
-  auto s_step = [&](SSet& n, const bf16x8& k0, const bf16x8& k1, int ks) {
-    if (ks == 0) { mfma_s0(n.a0, k0, qf[0][0]); mfma_s0(n.b0, k0, qf[1][0]); mfma_s0(n.a1, k1, qf[0][0]); mfma_s0(n.b1, k1, qf[1][0]); }
-    else { mfma_s(n.a0, k0, qf[0][ks]); mfma_s(n.b0, k0, qf[1][ks]); mfma_s(n.a1, k1, qf[0][ks]); mfma_s(n.b1, k1, qf[1][ks]); }
-  };
-  // fragment order of the S^T phase: index 2 ks + t  (k step ks, sub-tile t)
-  auto ldk2 = [&](const char* sK, int i) { return ldk(sK, (i & 1) * 8 + (i >> 1)); };
-  // start-softmax of both q-blocks, not interleaved (prologue only)
-  auto start_softmax = [&](SSet& n) {
-    float mxa = n.a0[0], mxb = n.b0[0];
-    mxa = max8(max8(max8(max8(mxa, n.a0, 0), n.a0, 8), n.a1, 0), n.a1, 8);
-    mxb = max8(max8(max8(max8(mxb, n.b0, 0), n.b0, 8), n.b1, 0), n.b1, 8);
-    rs_a = softmax_decide(half_swap_max(mxa), c, ma, al_a);
-    rs_b = softmax_decide(half_swap_max(mxb), c, mb, al_b);
-    const float mca = ma * c, mcb = mb * c;
-    fma8(n.a0, 0, c, mca); fma8(n.a0, 8, c, mca); fma8(n.a1, 0, c, mca); fma8(n.a1, 8, c, mca);
-    fma8(n.b0, 0, c, mcb); fma8(n.b0, 8, c, mcb); fma8(n.b1, 0, c, mcb); fma8(n.b1, 8, c, mcb);
-  };
-
-  // ---- prologue: K(0), V(0), K(1) in flight; S(0); start-softmax(0) ----
-#pragma unroll
-  for (int j = 0; j < KINS; ++j) dma_k(j, 0);
-#pragma unroll
-  for (int j = 0; j < VINS; ++j) dma_v(j, 0);
-#pragma unroll
-  for (int j = 0; j < KINS; ++j) dma_k(j, 1);
-  __builtin_amdgcn_s_waitcnt(0);     // (a wait hipcc sees: retires the Q loads in its own bookkeeping, see attn_fwd64_kernel)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  SSet X, Y;
-  {
-    bf16x8 kf[16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) kf[i] = ldk2(smem, i);
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      if (ks + 2 < 8) { kf[2 * ks + 4] = ldk2(smem, 2 * ks + 4); kf[2 * ks + 5] = ldk2(smem, 2 * ks + 5); }
-      s_step(X, kf[2 * ks], kf[2 * ks + 1], ks);
-    }
-  }
-  mfma_fence_v(X.a0, X.a1);
-  mfma_fence_v(X.b0, X.b1);
-  start_softmax(X);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();      // every wave has read K(0): its stage may take K(2)
-
-  // one tile: `cur` holds x(t) (start-softmax done), `nxt` receives S(t+1)
-  auto tile = [&](auto more_tag, SSet& cur, SSet& nxt, int kt) {
-    constexpr bool more = decltype(more_tag)::value;
-    const char* sKn = smem + ((kt + 1) & 1) * STAGE;
-    const char* sV = smem + (kt & 1) * STAGE + KTILE;
-    // ---------------- phase A: S(t+1) MFMAs | finish-softmax(t) | DMA issue of K(t+2), V(t+1) ----------------
-    STAMP(0);
-    float psa = 0.f, psb = 0.f;
-    bf16x8 kf[16];
-    if constexpr (more) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) kf[i] = ldk2(sKn, i);
-    }
-    // 32 slots: ONE MFMA, then the finish-softmax of two values (2 exp, 2 add, 1 packed word).  A lone wave issues in order, so VALU work
-    // only overlaps an MFMA if it sits right behind it: four MFMAs followed by twenty VALU instructions ran as 128 + 20 x 5 cycles.
-#pragma unroll
-    for (int sl = 0; sl < 32; ++sl) {
-      const int ks = sl >> 2, w = sl & 3;      // k step, (q-block, sub-tile) of this slot: a0 b0 a1 b1
-      if constexpr (more) {
-        if (w == 0 && ks + 2 < 8) kf[2 * ks + 4] = ldk2(sKn, 2 * ks + 4);
-        if (w == 2 && ks + 2 < 8) kf[2 * ks + 5] = ldk2(sKn, 2 * ks + 5);
-        f32x16& acc = w == 0 ? nxt.a0 : w == 1 ? nxt.b0 : w == 2 ? nxt.a1 : nxt.b1;
-        const bf16x8& kfr = kf[2 * ks + (w >> 1)];
-        if (ks == 0) mfma_s0(acc, kfr, qf[w & 1][0]);
-        else mfma_s(acc, kfr, qf[w & 1][ks]);
-      }
-      {   // word wi (two values) of q-block A for even slots, B for odd slots; words in ascending (sub-tile, row) order per q-block
-        const int wi = sl >> 1, t = wi >> 3, r0 = (wi & 7) * 2, f = 2 * t + (r0 >> 3), e = (r0 & 7) >> 1;
-        unsigned word = 0x3f803f80u;
-        if constexpr (!(V3A_PW_ABL & 16)) {
-          if ((sl & 1) == 0) { word = exp2w(t ? cur.a1 : cur.a0, r0, psa); PIN2(word, psa); }
-          else { word = exp2w(t ? cur.b1 : cur.b0, r0, psb); PIN2(word, psb); }
-        }
-        if ((sl & 1) == 0) pa[f][e] = word;
-        else pb[f][e] = word;
-      }
-      if ((sl & 3) == 3) STAMP(8 + (sl >> 2));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    STAMP(1);
-    // hipcc may copy S^T / O^T registers at the block boundaries that follow (they differ between the unrolled copies of this body):
-    // the copies are plain VALU / v_accvgpr reads, which need the MFMA results WRITTEN - fence here, while the matrix pipe still works
-    // off the last four MFMAs (found as wrong d-tile 3 of q-block A for even tile counts only)
-    if constexpr (more) pw_fence_s(nxt);
-    la = la * al_a + psa;
-    lb = lb * al_b + psb;
-    // ---------------- the rescale decided for THIS tile: O <- O alpha before its PV MFMAs ----------------
-    if (rs_a) {
-      mfma_fence_a(oa[0], oa[1], oa[2], oa[3]);
-#pragma unroll
-      for (int i = 0; i < DT; ++i) scale_acc(oa[i], al_a);
-    }
-    if (rs_b) {
-      mfma_fence_a(ob[0], ob[1], ob[2], ob[3]);
-#pragma unroll
-      for (int i = 0; i < DT; ++i) scale_acc(ob[i], al_b);
-    }
-    asm volatile("s_nop 3" :::);   // v_accvgpr_write'n O / VALU-written P -> MFMA operands
-    // ---------------- phase B: PV(t) MFMAs | start-softmax(t+1) ----------------
-    STAMP(2);
-    float mxa = 0.f, mxb = 0.f, mca = 0.f, mcb = 0.f;
-    bf16x8 vf[16];
-    vf[0] = ldv(sV, 0);
-    vf[1] = ldv(sV, 1);
-    // 32 slots: one PV MFMA, then its share of start-softmax(t+1): slots 4..19 row max (two values of A and B each, v_max3),
-    // slot 20 the two rescale decisions, slots 21..28 (odd/even: 8 values each) x = s c - m c, DMA pieces in slots 24..31
-#pragma unroll
-    for (int sl = 0; sl < 32; ++sl) {
-      const int j = sl >> 1;
-      if ((sl & 1) == 0 && j + 2 < 16) vf[j + 2] = ldv(sV, j + 2);
-      if ((sl & 1) == 0) mfma_o(oa[j & 3], vf[j], __builtin_bit_cast(bf16x8, pa[j >> 2]));
-      else mfma_o(ob[j & 3], vf[j], __builtin_bit_cast(bf16x8, pb[j >> 2]));
-      if constexpr (more && !(V3A_PW_ABL & 16)) {
-        if (sl == 3) { mxa = nxt.a0[0]; mxb = nxt.b0[0]; }
-        if (sl >= 4 && sl < 20) {
-          const int u = sl - 4, r0 = (u & 7) * 2;       // slots 4..11: sub-tile 0, 12..19: sub-tile 1
-          const f32x16& xa = (u >> 3) ? nxt.a1 : nxt.a0;
-          const f32x16& xb = (u >> 3) ? nxt.b1 : nxt.b0;
-          mxa = fmaxf(fmaxf(mxa, xa[r0]), xa[r0 + 1]);
-          mxb = fmaxf(fmaxf(mxb, xb[r0]), xb[r0 + 1]);
-          PIN2(mxa, mxb);
-        }
-        if (sl == 20) {
-          rs_a = softmax_decide(half_swap_max(mxa), c, ma, al_a);
-          rs_b = softmax_decide(half_swap_max(mxb), c, mb, al_b);
-          mca = ma * c;
-          mcb = mb * c;
-          PIN2(mca, mcb);
-        }
-        if (sl >= 21 && sl < 29) {
-          const int u = sl - 21;
-          f32x16& xs = u < 4 ? ((u >> 1) ? nxt.a1 : nxt.a0) : (((u - 4) >> 1) ? nxt.b1 : nxt.b0);
-          fma8(xs, (u & 1) * 8, c, u < 4 ? mca : mcb);
-          PIN1(xs);
-        }
-      }
-      if constexpr (more) {   // LDS-DMA of K(t+2) / V(t+1)
-        if (sl >= 24 && sl < 28) dma_k(sl - 24, kt + 2);
-        else if (sl >= 28) dma_v(sl - 28, kt + 1);
-      }
-      if (sl & 1) STAMP(16 + j);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    pw_fence_o(oa, ob);
-    // K(t+2) and V(t+1) have landed, every wave is done with K(t+1) and V(t)
-    STAMP(3);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    STAMP(4);
-    __builtin_amdgcn_s_barrier();
-    STAMP(5);
-  };
-  constexpr std::true_type MORE{};
-  constexpr std::false_type LAST{};
-  int kt = 0;
-  for (; kt + 2 <= nkt - 1; kt += 2) {
-    tile(MORE, X, Y, kt);
-    tile(MORE, Y, X, kt + 1);
-  }
-  if (kt < nkt - 1) {
-    tile(MORE, X, Y, kt);
-    tile(LAST, Y, X, kt + 1);
-  } else {
-    tile(LAST, X, Y, kt);
-  }
-
-  mfma_fence_a(oa[0], oa[1], oa[2], oa[3]);
-  mfma_fence_a(ob[0], ob[1], ob[2], ob[3]);
-  char* reg = smem + wave * (32 * OPITCH);
-  char* Ob = p.o + ((size_t)b * p.o_bs + (size_t)h * D) * 2;
-#pragma unroll
-  for (int qq = 0; qq < 2; ++qq) {
-    const float lx = qq ? lb : la;
-    const float inv = 1.0f / (lx + __shfl_xor(lx, 32, 64));
-#pragma unroll
-    for (int i = 0; i < DT; ++i) {
-      const f32x16& o = qq ? ob[i] : oa[i];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        u32x2 pk;
-        pk[0] = pack_bf16x2(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
-        pk[1] = pack_bf16x2(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
-        *(u32x2*)(reg + l31 * OPITCH + (i * 32 + g * 8 + hi * 4) * 2) = pk;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int idx = it * 64 + lane;
-      const int ql = idx / 16, ch = idx % 16;
-      const u32x2 lo = *(const u32x2*)(reg + ql * OPITCH + ch * 16);
-      const u32x2 hi2 = *(const u32x2*)(reg + ql * OPITCH + ch * 16 + 8);
-      const int qr = q0 + qq * 32 + ql;
-      if (qr < p.Nq) {
-        u32x4 v;
-        v[0] = lo[0]; v[1] = lo[1]; v[2] = hi2[0]; v[3] = hi2[1];
-        *(u32x4*)(Ob + ((size_t)qr * p.ldo) * 2 + ch * 16) = v;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-int launch_attn64(const AttnP& p, int B, void* stream, bool pipelined) {
-  constexpr int LDS = 2 * (64 * 256 + 128 * 128);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)attn_fwd64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return V3A_ERR_LAUNCH;
-    if (hipFuncSetAttribute((const void*)attn_fwd64p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return V3A_ERR_LAUNCH;
-    attr = true;
-  }
-  const int nqb = (p.Nq + 255) / 256;
-  if (pipelined) hipLaunchKernelGGL(attn_fwd64p_kernel, dim3((unsigned)(nqb * B * p.H)), dim3(256), LDS, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(attn_fwd64_kernel, dim3((unsigned)(nqb * B * p.H)), dim3(256), LDS, (hipStream_t)stream, p);
-  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
-}
-
-#endif   // V3A_ATTN_EXPERIMENTAL
 
 // Finish a key-split attention: one wave per (batch, query, head) merges the S partial softmaxes,
 //   O = sum_s 2^((m_s - M) c) O_s / sum_s 2^((m_s - M) c) l_s,   M = max_s m_s,
@@ -1425,13 +761,6 @@ int v3a_attn_combine_launch(const float* ws_o, const float* ws_ml, void* o, long
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
-static int g_attn_kernel = 0;
-extern "C" int v3a_attention_set_kernel(int which) {
-  const int prev = g_attn_kernel;
-  if (which >= 0 && which <= 3) g_attn_kernel = which;
-  return prev;
-}
-
 extern "C" size_t v3a_attention_split_workspace_bytes(int B, int H, int Nq, int D, int kv_split) {
   if (B <= 0 || H <= 0 || Nq <= 0 || D <= 0 || kv_split <= 1) return 0;
   return (size_t)kv_split * B * Nq * H * (D + 2) * sizeof(float);
@@ -1480,10 +809,6 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
     return launch_attn<128, 4, false, true, true>(p, a->B, stream);
   }
   if (a->D == 128) {
-#ifdef V3A_ATTN_EXPERIMENTAL
-    if (g_attn_kernel >= 2 && p.kv_split == 1 && !a->kv_seg && a->Nk % 64 == 0 && !a->kv_period && a->Nq >= 256)
-      return launch_attn64(p, a->B, stream, g_attn_kernel == 3);
-#endif
     if (two_per_cu) return launch_attn<128, 4, false, false, false>(p, a->B, stream);
     // a sequence-parallel shard (Nq = N / P queries against all N keys) has too few 128-query blocks to occupy 256 CUs: 64-query
     // workgroups double the count; per-wave arithmetic and key order are unchanged, so the output stays bit-identical

@@ -84,7 +84,8 @@ extern "C" int v3a_unipc_cfg_step(const v3a_unipc_step_args* a, void* stream) {
   if (a->corr_order < 0 || a->corr_order > 2 || a->pred_order < 1 || a->pred_order > 2) return V3A_ERR_ARG;
   if (a->corr_order > 0 && (!a->last_sample || !a->m_prev1)) return V3A_ERR_ARG;
   if ((a->corr_order == 2 && !a->m_prev2) || (a->pred_order == 2 && !a->m_prev1)) return V3A_ERR_ARG;
-  if (a->tok && (a->batch < 1 || a->batch > 2)) return V3A_ERR_ARG;
+  // dit_out holds `batch` row blocks of N tokens: the guided form reads rows [0, 2N) whether or not tok is written
+  if (a->batch < 1 || a->batch > 2 || (a->guided && a->batch != 2)) return V3A_ERR_ARG;
   const long total = (long)a->C * a->T * a->H * a->W;
   hipLaunchKernelGGL(unipc_cfg_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *a);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;

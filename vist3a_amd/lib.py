@@ -176,7 +176,6 @@ SYMBOLS = {
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "v3a_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "v3a_attention_set_kernel": (C.c_int, [C.c_int]),
     "v3a_unipc_cfg_step": (C.c_int, [C.POINTER(UniPCStepArgs), C.c_void_p]),
     "v3a_attention_fwd_fp8": (C.c_int, [C.POINTER(AttnFp8Args), C.c_void_p]),
     "v3a_gemm_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -212,7 +211,7 @@ SYMBOLS = {
 }
 
 _lib = None
-EXPECTED_ABI = 16   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
+EXPECTED_ABI = 17   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
 
 
 class HipLibraryError(RuntimeError):

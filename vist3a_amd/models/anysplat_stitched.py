@@ -102,9 +102,11 @@ class AnySplatStitched(torch.nn.Module):
         depth = out["depth"].view(1, S, H, W, 1)
         dconf = out["depth_conf"].view(1, S, H, W)
         U = g["means"].shape[0]
+        # anysplat_stitched.py:381-387: depth_conf > torch.quantile(depth_conf, conf_threshold) under render_conf, else all-true
+        valid = dconf > out["conf_valid"] if "conf_valid" in out else torch.ones_like(dconf, dtype=torch.bool)
         poses = [p[None] for p in out["pred_pose_enc_list"]]
         eo = EncoderOutput(gaussians=gauss, pred_pose_enc_list=poses, pred_context_pose=pose,
-                           depth_dict=dict(depth=depth, conf_valid_mask=torch.ones_like(dconf, dtype=torch.bool)),
+                           depth_dict=dict(depth=depth, conf_valid_mask=valid),
                            infos=dict(scene_scale=out["scene_scale"], voxelize_ratio=U / (H * W * S)), distill_infos=None,
                            last_pred_pose_enc=None if train else poses[-1])
         if not train:

@@ -628,6 +628,12 @@ def unipc_cfg_step(dit_out: torch.Tensor, tok: Optional[torch.Tensor], sample: t
         raise ValueError("sample must be contiguous f32 [1, C, T, H, W]")
     _, Cc, T, H, W = sample.shape
     N = T * (H // 2) * (W // 2)
+    if batch not in (1, 2) or (guidance is not None and batch != 2):
+        raise ValueError("batch must be 1 or 2, and 2 (cond | uncond row blocks) when guidance is given")
+    for name, t_ in (("dit_out", dit_out), ("tok", tok), ("last_sample", last_sample), ("m_prev1", m_prev1), ("m_prev2", m_prev2),
+                     ("m_out", m_out), ("sample_corrected", sample_corrected), ("prev", prev)):
+        if t_ is not None and t_.device != sample.device:
+            raise ValueError(f"{name} is on {t_.device}, the latents on {sample.device}")
     for name, t_ in (("m_out", m_out), ("sample_corrected", sample_corrected), ("prev", prev), ("last_sample", last_sample),
                      ("m_prev1", m_prev1), ("m_prev2", m_prev2)):
         if t_ is not None and (t_.dtype != f32 or not t_.is_contiguous() or t_.numel() != sample.numel()):

@@ -353,14 +353,18 @@ class ReconEngine:
         gsd = 1 + 7 + 3 * (cfg.sh_degree + 1) ** 2  # 83: density + raw gaussian; confidence sits in the next column
         out = dict(pred_pose_enc_list=poses, depth=depth, depth_conf=dconf, pts_all=pts, raw_gs=raw_gs, extrinsic_w2c=ext, intrinsic_px=K)
         M = S * H * W
+        c = None
+        if cfg.render_conf:
+            # the reference takes the quantile whenever render_conf is set (anysplat_stitched.py:381-387), also when the
+            # voxel branch then ignores the mask for the Gaussians: depth_dict["conf_valid_mask"] is returned either way (:494)
+            c = ops.conf_quantile_compact(dconf.reshape(M), cfg.conf_threshold, pts.view(M, 3), raw_gs, gsd)
+            out["conf_valid"] = c["threshold"]
         if cfg.voxelize:
             v = ops.voxelize_fuse(pts.view(M, 3), raw_gs, gsd, gsd, cfg.voxel_size)
             vp, vf = v["voxel_pts"], v["voxel_feat"]
             out.update(voxel_keys=v["keys"], voxel_inverse=v["inverse"], voxel_counts=v["counts"])
-        elif cfg.render_conf:
-            c = ops.conf_quantile_compact(dconf.reshape(M), cfg.conf_threshold, pts.view(M, 3), raw_gs, gsd)
+        elif c is not None:
             vp, vf = c["pts"], c["feat"]
-            out["conf_valid"] = c["threshold"]
         else:
             vp, vf = pts.view(M, 3), raw_gs[:, :gsd]
         out["gaussians"] = ops.gaussian_adapter(vp, vf, self.sh_mask, cfg.sh_degree, cfg.opacity_exponent)

@@ -115,6 +115,12 @@ def round_aggregator_to_bf16(sd: SD) -> SD:
     return sd
 
 
+# Linear / Conv2d modules of the reference's stitched_3d_model that add_lora wraps but the inference forward never runs
+# (anysplat.py:140-223: distillation copies, the point head of pred_head_type="point"; the rasteriser has no parameters).
+UNUSED_PREFIXES = ("encoder.distill_aggregator.", "encoder.distill_camera_head.", "encoder.distill_depth_head.",
+                   "encoder.point_head.", "decoder.")
+
+
 def merge_lora(sd: SD, lora_sd: SD, alpha: float, r: int) -> int:
     """Apply the `lora` entry of a stitched checkpoint (/root/reference/model_stitching_training.py:59-72 saves
     `lora_state_dict(model, bias="lora_only")`, utils/lora_util/utils.py:35-54) to the base weights `sd`, the way the reference's
@@ -123,7 +129,12 @@ def merge_lora(sd: SD, lora_sd: SD, alpha: float, r: int) -> int:
         W += (B @ A).view_as(W) * alpha / r  - what Linear.train(False) / ConvLoRA.train(False) do (layers.py:149-165,338-355);
       * every other key is a trained parameter of a LoRA-wrapped layer (its `bias`, also reachable as `<layer>.conv.bias` for a
         wrapped Conv2d) and REPLACES the base value.
-    A key that names nothing in `sd` raises: a silently dropped bias gives wrong reconstructions with no other symptom.
+    A key that names nothing in `sd` raises: a silently dropped bias (or a checkpoint whose keys carry a stray prefix such as
+    `module.` / `stitched_3d_model.`) gives wrong reconstructions with no other symptom.  The only keys skipped (with a warning) are
+    those under UNUSED_PREFIXES: modules the reference's add_lora wraps (it wraps every Linear / Conv2d of stitched_3d_model,
+    utils/lora_util/utils.py:148-153) but this inference path never executes.  add_lora runs AFTER convert_model_to_stitched_model
+    (nvs_eval.py:26-45), so a checkpoint never carries adapters for the dropped DINO blocks - those are not on the list.
+    A checkpoint with adapter matrices that merges none of them raises too.
     Returns the number of merged matrices.  Pinned by tests/golden/lora_tiny.safetensors (made by the reference's own code)."""
     n, unknown, absent = 0, [], []
     layers = {k.rsplit(".", 1)[0] for k in sd}
@@ -134,9 +145,10 @@ def merge_lora(sd: SD, lora_sd: SD, alpha: float, r: int) -> int:
 
     for key, v in lora_sd.items():
         if not layer_exists(key):
-            # the reference wraps EVERY Linear / Conv2d of stitched_3d_model with add_lora and loads with strict=False: a checkpoint may
-            # carry adapters for modules this engine does not keep (the dropped early DINO blocks, unused heads) - skipped, counted
-            absent.append(key)
+            if key.startswith(UNUSED_PREFIXES):
+                absent.append(key)
+            else:
+                unknown.append(key)
             continue
         if key.endswith("lora_B"):
             if key[: -len("lora_B")] + "lora_A" not in lora_sd:
@@ -163,4 +175,6 @@ def merge_lora(sd: SD, lora_sd: SD, alpha: float, r: int) -> int:
                       f"(e.g. {absent[0]})", stacklevel=2)
     if unknown:
         raise KeyError(f"LoRA checkpoint keys without a target in the base weights: {unknown[:8]}{' ...' if len(unknown) > 8 else ''}")
+    if n == 0 and any(k.endswith("lora_A") for k in lora_sd):
+        raise KeyError("LoRA checkpoint holds adapter matrices but none of them names a layer of this model")
     return n

@@ -130,8 +130,6 @@ class WanDiT:
         self._rope: Dict[tuple, torch.Tensor] = {}
         self._ctx: Dict[tuple, tuple] = {}  # (B, L, thread) -> (prompt key, persistent cross-attention K / V^T buffers)
         self.merge_padding_keys = True      # see _context
-        self.overlap_vt = False             # V^T GEMM on a second stream beside the q|k RMSNorm + RoPE pass (forward)
-        self._side = None
         # "fp8": self-attention on the block-scaled fp8 MFMA (BASELINE config #4; csrc/attention_fp8.hip): q / k (after RMSNorm + RoPE)
         # and V^T are rounded to e4m3 with the unit scales below.  "bf16" (default) is the reference's precision.
         self.attn_dtype = "bf16"
@@ -217,7 +215,7 @@ class WanDiT:
         self._tfreq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=f32) / half).to(dev)
 
     # ---------------------------------------------------------------- context (per prompt)
-    def _context(self, text: torch.Tensor, lane: int = 0):
+    def _context(self, text: torch.Tensor):
         """text [B,L,4096] -> per-block cross-attention K [B*L,d] and V^T [d,B*Lp] (+ key bias).  The results live in buffers that
         persist per (B, L) (so a captured hipGraph of `forward` stays valid across prompts) and are recomputed only when `text`
         changes.
@@ -227,7 +225,7 @@ class WanDiT:
         rows is represented by ONE key with an additive score bias log(c) — softmax over {k_1..k_n, c copies of k_pad} is
         softmax over {k_1..k_n, k_pad + log c} in exact arithmetic.  Cross-attention then runs over n+1 instead of 512 keys."""
         B, Lt, _ = text.shape
-        slot = (B, Lt, threading.get_ident(), lane)  # per thread: virtual ranks (seqpar.ThreadWorld) hold different prompts
+        slot = (B, Lt, threading.get_ident())  # per thread: virtual ranks (seqpar.ThreadWorld) hold different prompts
         # identity of the tensor OBJECT (kept alive by the cache entry, so its address cannot be recycled for another prompt's
         # embeddings while the entry is live) + its in-place version counter
         ent = self._ctx.get(slot)
@@ -271,13 +269,12 @@ class WanDiT:
     @torch.no_grad()
     def forward(self, hidden_states: Optional[torch.Tensor], timestep, encoder_hidden_states: torch.Tensor,
                 return_dict: bool = False, num_layers: Optional[int] = None, sp=None, tokens_in: bool = False, tokens_out: bool = False,
-                latent_shape: Optional[tuple] = None, time_table: Optional[tuple] = None, lane: int = 0):
+                latent_shape: Optional[tuple] = None, time_table: Optional[tuple] = None):
         """`sp` (wan/seqpar.py group) shards the latent tokens over sp.world ranks: every rank passes the SAME full
         `hidden_states` and gets the full prediction back; only N/P token rows are computed locally.
         Fused denoise loop (wan/pipeline.py): `tokens_in` = the patchified input already sits in `token_buffers()[0]` (written by
         ops.unipc_cfg_step; `hidden_states` may be None, `latent_shape` gives [B, C, T, H, W]); `tokens_out` = return the raw output
-        tokens (`token_buffers()[1]`) instead of the un-patchified tensor; `time_table` = this step's (temb, mod) from `time_tables()`;
-        `lane` selects an independent set of activation / prompt-context buffers (two forwards in flight on two streams)."""
+        tokens (`token_buffers()[1]`) instead of the un-patchified tensor; `time_table` = this step's (temb, mod) from `time_tables()`."""
         cfg = self.cfg
         B, C, Fr, Hh, Ww = hidden_states.shape if hidden_states is not None else latent_shape
         pt, ph, pw = cfg.patch_size
@@ -287,7 +284,7 @@ class WanDiT:
         if N % P or (P > 1 and (N // P) % 8):
             raise ValueError(f"{N} tokens do not split into {P} shards of a multiple of 8 rows")
         Nl = N // P  # local tokens [rk*Nl, (rk+1)*Nl) of every batch item
-        wkey = (B, N, P, rk, threading.get_ident(), lane)  # per thread: virtual ranks (seqpar.ThreadWorld) must not share buffers
+        wkey = (B, N, P, rk, threading.get_ident())  # per thread: virtual ranks (seqpar.ThreadWorld) must not share buffers
         ws = self._ws.get(wkey)
         if ws is None:
             ws = self._ws[wkey] = _Workspace(B, Nl, N, P, cfg, self.device)
@@ -295,7 +292,7 @@ class WanDiT:
         if rope is None:
             rope = self._rope[(ppf, pph, ppw)] = rope_table(cfg, ppf, pph, ppw, self.device)
         rope = rope[rk * Nl:(rk + 1) * Nl]
-        ks, vts, Lt, Lp, kbias, Lk, merged = self._context(encoder_hidden_states, lane)
+        ks, vts, Lt, Lp, kbias, Lk, merged = self._context(encoder_hidden_states)
 
         # patchify: Conv3d(k=s=(1,2,2)) == GEMM over (c,pt,ph,pw)-major patches
         if not tokens_in:
@@ -350,7 +347,6 @@ class WanDiT:
         for li in range(nl):
             b, m = self.blocks[li], mod[li]
             # --- self attention
-            vt_done = None
             norm(scale=m[:, 1], shift=m[:, 0], rows_per_batch=Nl)
             if P == 1:
                 lin(ws.n, b, "wqk", b["bqk"], out=ws.qk)
@@ -360,21 +356,7 @@ class WanDiT:
                         ops.gemm(b["wv8"], ws.a8[r0:r1], b["bv"], out=ws.vt if vbs == N else ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True,
                                  a_scale=b["swv"], w_scale=ws.sa[r0:r1])
                 elif vbs == N:  # no per-item padding: V^T of the whole batch is one [d, B*N] GEMM (256 tiles of 192x256 at 1.3B)
-                    if self.overlap_vt and self.attn_dtype != "fp8":
-                        # V^T on a second stream, ordered behind the q|k GEMM: it then runs beside the HBM-bound RMSNorm + RoPE pass over
-                        # q|k (whose waves fit next to the GEMM's on a CU) instead of in front of it
-                        main = torch.cuda.current_stream()
-                        if self._side is None:
-                            self._side = torch.cuda.Stream(device=self.device)
-                        e_qk = torch.cuda.Event()
-                        e_qk.record(main)
-                        self._side.wait_event(e_qk)
-                        with torch.cuda.stream(self._side):
-                            ops.gemm(b["wv"], ws.n, b["bv"], out=ws.vt, bias_row=True)
-                            vt_done = torch.cuda.Event()
-                            vt_done.record(self._side)
-                    else:
-                        ops.gemm(b["wv"], ws.n, b["bv"], out=ws.vt, bias_row=True)
+                    ops.gemm(b["wv"], ws.n, b["bv"], out=ws.vt, bias_row=True)
                 else:
                     for bi in range(B):
                         ops.gemm(b["wv"], ws.n[bi * N:(bi + 1) * N], b["bv"], out=ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True)
@@ -395,8 +377,6 @@ class WanDiT:
                                       k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d, q_scale=qs, k_scale=ksc, v_scale=vs)
                 else:
                     ops.rmsnorm_rope(ws.qk, b["nq"], out=ws.qk, rope=rope, head_dim=hd, tokens_per_batch=N, eps=cfg.eps, weight2=b["nk"])
-                    if vt_done is not None:
-                        torch.cuda.current_stream().wait_event(vt_done)
                     ops.attention(q, k, ws.vt, ws.ao, B=B, H=H, Nq=N, Nk=N, D=hd, q_batch_stride=N * 2 * d,
                                   k_batch_stride=N * 2 * d, vt_batch_stride=vbs, o_batch_stride=N * d)
             else:
@@ -501,22 +481,26 @@ class WanDiT:
     def time_tables(self, timesteps: torch.Tensor, B: int):
         """The time conditioning of a whole schedule at once: it depends on the timestep only, so the fused denoise loop computes it
         for all S steps in ONE pass of the embedder (three skinny GEMMs over S rows) instead of S passes over B identical rows.
-        -> list of S (temb [B, d], mod [L, B, 6, d]) pairs, bit-identical per step to `_time_conditioning(t.expand(B))`."""
+        -> list of S (temb [B, d], mod [L, B, 6, d]) pairs, bit-identical per step to `_time_conditioning(t.expand(B))` (asserted at the
+        1.3B / 14B widths by tests/test_dit_gpu.py::test_time_tables_bit_identical_at_production_width).  The modulation of the whole
+        schedule is ONE [L, S, 6, d] f32 tensor (55 MB at 1.3B x 50 steps); a step's table is a stride-0 view of it over the batch
+        dimension - the LayerNorm / GEMM kernels take the per-batch row stride of the scale / shift / gate operands, so nothing is
+        materialised per step or per batch item."""
         t = timesteps.to(device=self.device, dtype=f32)
         out = []
         for s0 in range(0, t.shape[0], 64):   # (<= 128 rows per skinny GEMM)
             temb, mod = self._time_conditioning(t[s0:s0 + 64], B)
             for i in range(temb.shape[0]):
-                out.append((temb[i:i + 1].expand(B, -1).contiguous(), mod[:, i:i + 1].expand(-1, B, -1, -1).contiguous()))
+                out.append((temb[i:i + 1].expand(B, -1), mod[:, i:i + 1].expand(-1, B, -1, -1)))
         return out
 
-    def token_buffers(self, B: int, latent_shape: tuple, lane: int = 0):
+    def token_buffers(self, B: int, latent_shape: tuple):
         """(input tokens [B N, 64] bf16, output tokens [B N, 64] bf16) of the workspace `forward` uses for this shape on this thread."""
         cfg = self.cfg
         _, C, Fr, Hh, Ww = latent_shape
         pt, ph, pw = cfg.patch_size
         N = (Fr // pt) * (Hh // ph) * (Ww // pw)
-        wkey = (B, N, 1, 0, threading.get_ident(), lane)
+        wkey = (B, N, 1, 0, threading.get_ident())
         ws = self._ws.get(wkey)
         if ws is None:
             ws = self._ws[wkey] = _Workspace(B, N, N, 1, cfg, self.device)

@@ -39,7 +39,18 @@ class WanT2VPipeline:
         self.text_encoder = text_encoder
         self.device = torch.device(device)
 
-    fused = True   # one launch per step for guidance + UniPC + (un)patchify (csrc/denoise_step.hip); False = the tensor-op loop below
+    # One launch per step for guidance + UniPC + (un)patchify (csrc/denoise_step.hip); False = the tensor-op loop below.
+    # The fused loop is taken only when `_can_fuse()` holds (a plain WanDiT, patch (1,2,2), no sequence-parallel plan, no callback,
+    # solver_order <= 2 - the orders plan_step implements); a GraphedWanDiT transformer has no token buffers and runs the tensor-op
+    # loop.  The fused loop drives the scheduler through plan_step() only: scheduler.step() is never called, so
+    # `scheduler.model_outputs` / `.last_sample` are NOT updated by it (step_index / lower_order_nums are).
+    fused = True
+
+    def _can_fuse(self, callback) -> bool:
+        sch, tr = self.scheduler, self.transformer
+        return (self.fused and self.plan is None and callback is None and hasattr(tr, "token_buffers")
+                and tuple(getattr(tr.cfg, "patch_size", ())) == (1, 2, 2) and hasattr(sch, "plan_step")
+                and getattr(sch, "solver_order", 3) <= 2)
 
     def _fused_loop(self, latents: torch.Tensor, text: torch.Tensor, nb: int, shape: tuple, guidance: Optional[float]) -> torch.Tensor:
         """The denoise loop with everything between two DiT forwards in ONE kernel (ops.unipc_cfg_step) and the time conditioning of
@@ -110,8 +121,7 @@ class WanT2VPipeline:
             text = prompt_embeds.to(self.device).contiguous()
         nb = text.shape[0]
         pair = torch.empty((2,) + shape, device=self.device, dtype=torch.bfloat16) if cfgp is not None else None
-        if self.fused and self.plan is None and callback is None and hasattr(self.transformer, "token_buffers") \
-                and tuple(getattr(self.transformer.cfg, "patch_size", ())) == (1, 2, 2) and hasattr(self.scheduler, "plan_step"):
+        if self._can_fuse(callback):
             latents = self._fused_loop(latents, text, nb, shape, guidance_scale if do_cfg else None)
             if output_type == "latent":
                 return {"frames": latents}
