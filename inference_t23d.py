@@ -27,7 +27,7 @@ from vist3a_amd.utils.argument import inference_vist3a_argument  # noqa: E402
 from vist3a_amd.utils.dist_util import setup_dist, shard_prompts  # noqa: E402
 from vist3a_amd.utils.ply_export import export_ply  # noqa: E402
 from vist3a_amd.wan.dit import WAN_1_3B, WAN_14B, WanDiT  # noqa: E402
-from vist3a_amd.wan.weights import load_dit_state_dict, load_peft_lora, random_dit_state_dict  # noqa: E402
+from vist3a_amd.wan.weights import load_dit_config, load_dit_state_dict, load_peft_lora, random_dit_state_dict  # noqa: E402
 
 PROMPT_TEMPLATE = "The camera rotates around the scene, maintaining constant distance: `{}`. The orbiting trajectory captures 3D structure and consistency."
 NEGATIVE_PROMPT = ("Background blur, Blurred background, Blurred scene, Artifacts, not aesthetic, not realistic, rendered noise, low quality movement, "
@@ -40,6 +40,7 @@ def build_transformer(args, device):
     if args.checkpoint_path == "synthetic" and not os.path.isdir(args.model_id):
         sd = random_dit_state_dict(cfg, seed=0, device=str(device))
     else:
+        cfg = load_dit_config(args.model_id, cfg)   # <model_id>/transformer/config.json, as diffusers' from_pretrained
         sd = load_dit_state_dict(args.model_id)
     if args.transformer_lora_path not in ("none", "", None):
         load_peft_lora(args.transformer_lora_path, sd)  # merged at load: W += (alpha/r) B A

@@ -11,6 +11,15 @@ PARITY PINNED: tests/golden/vae_decode_tiny.safetensors / vae_encode_tiny.safete
 module itself (tests/golden/make_golden.py, stub-imported in the build container) on weights from `make_weights` /
 `make_encoder_weights` below.
 
+`emulate_bf16=True` (decode / encode) restates the SAME arithmetic with the rounding points the reference has when it runs under
+`torch.autocast("cuda", dtype=torch.bfloat16)` (/root/reference/inference_t23d.py:87-114; op lists of CUDA autocast): every
+conv3d / conv2d takes bf16 inputs and bf16 weights and returns bf16 (fp32 accumulation); `WanRMS_norm` (F.normalize: on autocast's
+fp32 list) and the SiLU behind it run in fp32 and are rounded when the next conv casts its input; residual sums of two bf16
+tensors are bf16; scaled_dot_product_attention runs on bf16 q / k / v with a bf16 probability operand (flash kernel) and returns
+bf16; the nearest-exact upsample is exact.  The fp32 default stays the parity-pinned form (goldens); the emulation is the "kernel
+contract" the HIP decoder is held to at production size (tests/test_fullsize_gpu.py).  It cannot be pinned by executing the
+reference (no CUDA device here; CPU autocast has different op lists) - the rounding points are derived by reading.
+
 The reference decodes one latent frame per call and threads a cache of the last two input frames through every
 causal conv.  That is arithmetically a causal convolution over the whole frame sequence (two zero frames in
 front), with ONE quirk that this restatement keeps: in `upsample3d` the first latent frame skips `time_conv`
@@ -49,10 +58,31 @@ class WanVAEConfig:
         return dims[0], plan
 
 
+_EMU = False   # set for the duration of decode(..., emulate_bf16=True) / encode(..., emulate_bf16=True)
+
+
+def _r(x: torch.Tensor) -> torch.Tensor:
+    """bf16 rounding point of the CUDA-autocast contract (identity in the fp32 default)"""
+    return x.to(torch.bfloat16).float() if _EMU else x
+
+
+def sdpa_bf16p(q, k, v):
+    """softmax(q k^T / sqrt(d)) v with the probability operand rounded to bf16 and the row sum taken over the unrounded values -
+    the contract of every flash kernel on bf16 inputs (the reference's CUDA SDPA included).  q, k, v [..., N, d] fp32 (bf16 values)."""
+    s = (q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+    p = torch.exp(s - s.amax(-1, keepdim=True))
+    l = p.sum(-1, keepdim=True)
+    return (p.to(torch.bfloat16).float() @ v) / l
+
+
 def causal_conv3d(x, w, b, pad):
     """x [B,C,T,H,W]; zero pad (W,W,H,H,2*pT,0) then valid conv (WanCausalConv3d.forward without cache)."""
     pt, ph, pw = pad
-    return F.conv3d(F.pad(x, (pw, pw, ph, ph, 2 * pt, 0)), w, b)
+    return _r(F.conv3d(F.pad(_r(x), (pw, pw, ph, ph, 2 * pt, 0)), _r(w), _r(b)))
+
+
+def conv2d(x, w, b, **kw):
+    return _r(F.conv2d(_r(x), _r(w), _r(b), **kw))
 
 
 def rms_norm(x, gamma, dim=1):
@@ -67,7 +97,7 @@ def res_block(sd, p, x):
     x = causal_conv3d(x, sd[p + "conv1.weight"], sd[p + "conv1.bias"], (1, 1, 1))
     x = F.silu(rms_norm(x, sd[p + "norm2.gamma"]))
     x = causal_conv3d(x, sd[p + "conv2.weight"], sd[p + "conv2.bias"], (1, 1, 1))
-    return x + h
+    return _r(x + h)
 
 
 def attn_block(sd, p, x):
@@ -75,13 +105,13 @@ def attn_block(sd, p, x):
     idn = x
     y = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
     y = rms_norm(y, sd[p + "norm.gamma"])
-    qkv = F.conv2d(y, sd[p + "to_qkv.weight"], sd[p + "to_qkv.bias"])
+    qkv = conv2d(y, sd[p + "to_qkv.weight"], sd[p + "to_qkv.bias"])
     qkv = qkv.reshape(B * T, 1, C * 3, -1).permute(0, 1, 3, 2).contiguous()
     q, k, v = qkv.chunk(3, dim=-1)
-    y = F.scaled_dot_product_attention(q, k, v)
+    y = _r(sdpa_bf16p(q, k, v)) if _EMU else F.scaled_dot_product_attention(q, k, v)
     y = y.squeeze(1).permute(0, 2, 1).reshape(B * T, C, H, W)
-    y = F.conv2d(y, sd[p + "proj.weight"], sd[p + "proj.bias"])
-    return y.view(B, T, C, H, W).permute(0, 2, 1, 3, 4) + idn
+    y = conv2d(y, sd[p + "proj.weight"], sd[p + "proj.bias"])
+    return _r(y.view(B, T, C, H, W).permute(0, 2, 1, 3, 4) + idn)
 
 
 def resample(sd, p, x, mode):
@@ -94,12 +124,22 @@ def resample(sd, p, x, mode):
         T = x.shape[2]
     y = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
     y = F.interpolate(y.float(), scale_factor=(2.0, 2.0), mode="nearest-exact")
-    y = F.conv2d(y, sd[p + "resample.1.weight"], sd[p + "resample.1.bias"], padding=1)
+    y = conv2d(y, sd[p + "resample.1.weight"], sd[p + "resample.1.bias"], padding=1)
     return y.view(B, T, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
 
 
-def decode(sd: Dict[str, torch.Tensor], cfg: WanVAEConfig, z: torch.Tensor) -> torch.Tensor:
-    """AutoencoderKLWan._decode: z [B,16,T_lat,h,w] (de-normalised latents) -> video [B,3,1+4(T_lat-1),8h,8w] in [-1,1]."""
+def decode(sd: Dict[str, torch.Tensor], cfg: WanVAEConfig, z: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
+    """AutoencoderKLWan._decode: z [B,16,T_lat,h,w] (de-normalised latents) -> video [B,3,1+4(T_lat-1),8h,8w] in [-1,1].
+    emulate_bf16: the CUDA-autocast rounding points (module docstring)."""
+    global _EMU
+    prev, _EMU = _EMU, bool(emulate_bf16)
+    try:
+        return _decode(sd, cfg, z)
+    finally:
+        _EMU = prev
+
+
+def _decode(sd, cfg, z):
     sd = {k: v.float() for k, v in sd.items()}
     x = causal_conv3d(z.float(), sd["post_quant_conv.weight"], sd["post_quant_conv.bias"], (0, 0, 0))
     d = "decoder."
@@ -185,17 +225,26 @@ def downsample(sd, p, x, mode):
     stride-2 (3,1,1) conv over [last cached frame, chunk] — i.e. out[0] = y[0], out[k] = conv(y[2k-2], y[2k-1], y[2k])."""
     B, C, T, H, W = x.shape
     y = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
-    y = F.conv2d(F.pad(y, (0, 1, 0, 1)), sd[p + "resample.1.weight"], sd[p + "resample.1.bias"], stride=2)
+    y = conv2d(F.pad(y, (0, 1, 0, 1)), sd[p + "resample.1.weight"], sd[p + "resample.1.bias"], stride=2)
     y = y.view(B, T, C, y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
     if mode == "downsample3d" and T > 1:
-        rest = F.conv3d(y, sd[p + "time_conv.weight"], sd[p + "time_conv.bias"], stride=(2, 1, 1))
+        rest = _r(F.conv3d(_r(y), _r(sd[p + "time_conv.weight"]), _r(sd[p + "time_conv.bias"]), stride=(2, 1, 1)))
         y = torch.cat([y[:, :, :1], rest], 2)
     return y
 
 
-def encode(sd: Dict[str, torch.Tensor], cfg: WanVAEConfig, x: torch.Tensor) -> torch.Tensor:
+def encode(sd: Dict[str, torch.Tensor], cfg: WanVAEConfig, x: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
     """AutoencoderKLWan._encode: video [B,3,1+4n,H,W] in [-1,1] -> posterior parameters [B,2*z_dim,1+n,H/8,W/8]
     (mean | logvar).  Every causal conv over chunk+cache equals a causal conv over the whole clip (zero frames in front)."""
+    global _EMU
+    prev, _EMU = _EMU, bool(emulate_bf16)
+    try:
+        return _encode(sd, cfg, x)
+    finally:
+        _EMU = prev
+
+
+def _encode(sd, cfg, x):
     sd = {k: v.float() for k, v in sd.items()}
     e = "encoder."
     x = causal_conv3d(x.float(), sd[e + "conv_in.weight"], sd[e + "conv_in.bias"], (1, 1, 1))

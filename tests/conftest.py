@@ -11,6 +11,14 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `-m gpu`)")
+    # pytest.ini runs the suite on 4 xdist workers (the wall time of `-m gpu` is the CPU oracle at production size: ~10 min serial).
+    # Each worker's torch CPU pool gets half the host's threads: at most two or three oracle-heavy tests overlap at any time.
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        try:
+            import torch
+            torch.set_num_threads(max(4, (os.cpu_count() or 8) // 2))
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def _has_gpu() -> bool:
@@ -58,11 +66,21 @@ def parity():
 
 
 def pytest_sessionfinish(session, exitstatus):
-    if not _PARITY.rows:
-        return
     import json
     out = Path(os.environ.get("V3A_PARITY_JSON", ROOT / "gpurun_out" / "parity.json"))
+    worker = os.environ.get("PYTEST_XDIST_WORKER")
     try:
+        if worker:   # an xdist worker: leave its rows for the controller (whose sessionfinish runs after every worker's)
+            if _PARITY.rows:
+                out.parent.mkdir(parents=True, exist_ok=True)
+                out.with_name(f"{out.stem}.{worker}.part").write_text(json.dumps(_PARITY.rows))
+            return
+        rows = list(_PARITY.rows)
+        for part in sorted(out.parent.glob(f"{out.stem}.*.part")):
+            rows += json.loads(part.read_text())
+            part.unlink()
+        if not rows:
+            return
         out.parent.mkdir(parents=True, exist_ok=True)
         meta = {}
         try:
@@ -70,6 +88,6 @@ def pytest_sessionfinish(session, exitstatus):
             meta = dict(device=torch.cuda.get_device_name(0), torch=torch.__version__)
         except Exception:  # noqa: BLE001
             pass
-        out.write_text(json.dumps(dict(meta=meta, rows=_PARITY.rows), indent=1))
+        out.write_text(json.dumps(dict(meta=meta, rows=sorted(rows, key=lambda r: r.get("test", ""))), indent=1))
     except OSError:
         pass

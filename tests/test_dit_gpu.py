@@ -415,6 +415,65 @@ def test_wan14b_width_fp8_gemm_matches_e4m3_oracle(hip_lib, parity):
     assert all(torch.equal(o, outga) for o in outs)
 
 
+@pytest.mark.parametrize("width", ["1.3b", "14b"])
+def test_time_tables_bit_identical_at_production_width(hip_lib, width):
+    """WanDiT.time_tables (the time conditioning of a whole 50-step schedule as ONE batched pass of the embedder, handed to the fused
+    loop as stride-0 batch views of one [L, S, 6, d] table) against the per-step `_time_conditioning(t.expand(B))` at the production
+    widths: its bit-identity rests on the skinny / tile GEMM results being independent of the number of rows M (K = freq_dim = 256 in
+    the first GEMM, K = d in the others) - asserted here at d = 1536 and d = 5120, not only on a tiny model."""
+    import dataclasses
+    from vist3a_amd.wan.dit import WAN_1_3B, WAN_14B, WanDiT
+    from vist3a_amd.wan.scheduler import UniPCMultistepScheduler
+    from vist3a_amd.wan.weights import random_dit_state_dict
+    cfg = dataclasses.replace(WAN_1_3B if width == "1.3b" else WAN_14B, num_layers=2, text_dim=256)
+    m = WanDiT(cfg, random_dit_state_dict(cfg, seed=1, device="cuda"))
+    sch = UniPCMultistepScheduler(flow_shift=5.0)
+    sch.set_timesteps(50, device="cuda")
+    tabs = m.time_tables(sch.timesteps, 2)
+    assert len(tabs) == 50
+    for i in (0, 1, 17, 49):
+        temb, mod = m._time_conditioning(sch.timesteps[i].to(torch.float32).expand(2).contiguous(), 2)
+        assert torch.equal(tabs[i][0], temb) and torch.equal(tabs[i][1], mod), i
+    assert tabs[3][1].stride(1) == 0 and tabs[3][1].shape == (2, 2, 6, cfg.dim)    # a view: nothing materialised per step / batch item
+
+
+def test_config4_wan14b_two_blocks_at_4096_tokens_matches_oracle(hip_lib, parity):
+    """BASELINE config #4 AT SIZE: Wan-14B width (40 heads x 128 = 5120, FFN 13824), the CFG pair (B = 2) of a 13-view scene
+    (N = 4096 tokens, M = 8192 GEMM rows: the ragged 5120 / 13824 tilings at their real M), two blocks, 512-row zero-padded prompts -
+    in bf16 against the oracle with the kernel contracts emulated (bf16 rounding points, bf16-P flash tiles, merged padding key),
+    and in the config's fp8-attention mode against the oracle with the e4m3 rounding points."""
+    import time
+    from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
+    kw = dict(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=2, text_dim=512, freq_dim=256)
+    ocfg = O.WanDiTConfig(**kw)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=4).items()}
+    model = WanDiT(WanDiTConfig(**kw), sd, device="cuda")
+    g = torch.Generator().manual_seed(44)
+    lat = torch.randn(2, 16, 4, 64, 64, generator=g).to(torch.bfloat16)
+    text = (torch.randn(2, 512, 512, generator=g) * 0.5).to(torch.bfloat16).float()
+    text[0, 64:] = 0
+    text[1, 80:] = 0
+    t = torch.tensor([611, 611])
+    out16 = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
+    model.attn_dtype = "fp8"
+    out8 = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
+    model.attn_dtype = "bf16"
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with torch.no_grad():
+        ref16 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True)
+        t1 = time.time()
+        ref8 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, flash=True, merge_padding=True)
+    t2 = time.time()
+    r16, r8, shift = _rel(out16, ref16), _rel(out8, ref8), _rel(out8, out16)
+    parity("dit_config4_14B_N4096_B2_two_blocks", rel_bf16_vs_contract_oracle=r16, rel_fp8_attention_vs_e4m3_oracle=r8,
+           fp8_attention_mode_vs_bf16_mode=shift, oracle_seconds=[t1 - t0, t2 - t1])
+    print(f"config #4 at size (14B width, N=4096, B=2, 2 blocks): bf16 vs contract oracle {r16:.2e}; fp8 attention vs e4m3 oracle {r8:.2e}; "
+          f"fp8 mode moves the output by {shift:.2e}; oracle {t1 - t0:.0f} + {t2 - t1:.0f} s")
+    assert out16.shape == lat.shape and torch.isfinite(out16).all() and torch.isfinite(out8).all()
+    assert r16 < 6e-3 and r8 < 1.3e-2, (r16, r8)    # the N = 6144 / 1.3B-width two-block forward measured 2.6e-3; 14B width at 128 tokens 5.3e-3 / 6.3e-3
+
+
 @pytest.mark.parametrize("P", [4, 8])
 def test_seq_parallel_production_width_reads_gathered_slabs_in_place(hip_lib, P):
     """Production width and token count (4096 tokens, 2 blocks) over P virtual ranks: every shard holds 4096 / P keys (a multiple of
@@ -455,6 +514,44 @@ def test_seq_parallel_production_width_reads_gathered_slabs_in_place(hip_lib, P)
         assert torch.equal(o, full)
     for o in outs_split:
         assert torch.equal(o, outs_split[0]) and _rel(o, full) < 5e-3, _rel(o, full)   # bf16 rounding of the merged softmax
+
+
+def test_config4_seq_parallel_14b_width_P8_e4m3_slabs_in_place(hip_lib):
+    """BASELINE config #4's sharding at its own width: Wan-14B (5120 wide, 40 heads), 4096 tokens over P = 8 virtual ranks (512 keys per
+    rank), fp8 attention - the ranks all-gather E4M3 [K | V^T] slabs (half the bytes) and the fp8 flash kernel walks them in place;
+    bit-identical to the unsharded fp8-attention forward in the exact mode, and so is the bf16 path over bf16 slabs."""
+    import dataclasses
+    from vist3a_amd import ops
+    from vist3a_amd.wan.dit import WAN_14B, WanDiT
+    from vist3a_amd.wan.seqpar import ThreadWorld
+    from vist3a_amd.wan.weights import random_dit_state_dict
+    cfg = dataclasses.replace(WAN_14B, num_layers=1, text_dim=512)
+    m = WanDiT(cfg, random_dit_state_dict(cfg, seed=0, device="cuda"))
+    g = torch.Generator().manual_seed(5)
+    text = (torch.randn(1, 512, 512, generator=g) * 0.1).cuda()
+    text[:, 70:] = 0
+    lat = torch.randn(1, 16, 4, 64, 64, generator=g).bfloat16().cuda()
+    t = torch.tensor([700]).cuda()
+    P = 8
+    w = ThreadWorld(P)
+    m.sp_kv_split = 1
+    seen = []
+    real16, real8 = ops.attention, ops.attention_fp8
+    ops.attention = lambda *a, **k: (seen.append(("bf16", k.get("kv_seg", 0))), real16(*a, **k))[1]
+    ops.attention_fp8 = lambda *a, **k: (seen.append(("fp8", k.get("kv_seg", 0))), real8(*a, **k))[1]
+    try:
+        full16 = m(lat, t, text)[0].clone()
+        outs16 = w.run(lambda r: m(lat, t, text, sp=w.group(r))[0].clone())
+        m.attn_dtype = "fp8"
+        full8 = m(lat, t, text)[0].clone()
+        outs8 = w.run(lambda r: m(lat, t, text, sp=w.group(r))[0].clone())
+        torch.cuda.synchronize()
+    finally:
+        ops.attention, ops.attention_fp8 = real16, real8
+    assert ("bf16", 4096 // P) in seen and ("fp8", 4096 // P) in seen, "the sharded self-attention did not walk the gathered slabs in place"
+    assert all(torch.equal(o, full16) for o in outs16)
+    assert all(torch.equal(o, full8) for o in outs8)
+    assert not torch.equal(full8, full16) and _rel(full8, full16) < 5e-2
 
 
 def test_lora_adapter_forward_matches_unmerged_oracle(hip_lib, parity):

@@ -25,25 +25,42 @@ def _rel(a, b):
 
 
 def test_full_size_vae_decode_matches_oracle(hip_lib, parity):
+    """Primary gate: the HIP decoder against the oracle with the reference's GPU rounding points (`emulate_bf16`: CUDA-autocast bf16
+    convs / SDPA, fp32 WanRMS_norm + SiLU; oracle/wan_vae.py docstring) at production size.  The fp32 figure is informational and
+    taken on a quarter-size clip (same 96-wide network, latent [1,16,2,32,32] -> 5 x 256^2) where both oracle forms run in seconds:
+    it shows how far bf16 rounding alone moves this network (oracle-contract vs oracle-fp32) next to HIP vs either."""
+    import time
     from vist3a_amd.wan.vae import WanVAEConfig, WanVAEDecoder
     cfg = OV.WanVAEConfig()
     assert cfg.base_dim == 96
     sd = OV.make_weights(cfg, seed=31)
-    z = torch.randn(1, 16, 4, 64, 64, generator=torch.Generator().manual_seed(32))
     dec = WanVAEDecoder(WanVAEConfig(), sd)
+    zs = torch.randn(1, 16, 2, 32, 32, generator=torch.Generator().manual_seed(33))
+    outs = dec.decode(zs.cuda(), return_dict=False)[0].float().cpu()
+    with torch.no_grad():
+        rs32, rsc = OV.decode(sd, cfg, zs), OV.decode(sd, cfg, zs, emulate_bf16=True)
+    small = dict(rel_vs_contract=_rel(outs, rsc), rel_vs_fp32=_rel(outs, rs32), contract_vs_fp32=_rel(rsc, rs32))
+    z = torch.randn(1, 16, 4, 64, 64, generator=torch.Generator().manual_seed(32))
     out = dec.decode(z.cuda(), return_dict=False)[0].float().cpu()
     torch.cuda.synchronize()
+    t0 = time.time()
     with torch.no_grad():
-        ref = OV.decode(sd, cfg, z)
+        ref = OV.decode(sd, cfg, z, emulate_bf16=True)
+    t_oracle = time.time() - t0
     assert out.shape == ref.shape == (1, 3, 13, 512, 512)
     r = _rel(out, ref)
     sat = (ref.abs() >= 1.0).float().mean().item()
     mx = (out - ref).abs().max().item()
-    parity("vae_decode_full_size_base96", rel_vs_oracle=r, max_abs=mx, clamped_fraction=sat)
-    print(f"full-size VAE decode (base_dim 96, 13 x 512^2): rel {r:.3e} max abs {mx:.3e} clamped {sat:.3f}")
+    parity("vae_decode_full_size_base96", rel_vs_contract_oracle=r, max_abs=mx, clamped_fraction=sat, quarter_size=small, oracle_seconds=t_oracle)
+    print(f"full-size VAE decode (base_dim 96, 13 x 512^2): rel vs contract oracle {r:.3e} max abs {mx:.3e} clamped {sat:.3f} "
+          f"(oracle {t_oracle:.0f} s); quarter size: vs contract {small['rel_vs_contract']:.3e}, vs fp32 {small['rel_vs_fp32']:.3e}, "
+          f"contract vs fp32 {small['contract_vs_fp32']:.3e}")
     assert torch.isfinite(out).all() and sat < 0.5
-    assert r < 2.6e-2, r      # measured 1.34e-2 on MI355X (profiles/r3/parity.json): 35 bf16 conv layers + bf16 activations vs fp32
-    #                           (the same 1.3e-2 .. 1.6e-2 as at base_dim 16 against the reference golden: depth, not width, sets it)
+    assert r < VAE_FULL_GATE and small["rel_vs_contract"] < VAE_FULL_GATE, (r, small)
+    assert small["rel_vs_fp32"] < 2.6e-2        # informational figure, round-3 gate (1.3e-2 measured at full size)
+
+
+VAE_FULL_GATE = 1.0e-2    # <= 2x the measured HIP-vs-contract figure (set from the first MI355X run of this test, see profiles/r4/parity.json)
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +84,11 @@ def _stitched(sd, rcfg_kw, C, res=512):
 
 
 def test_full_size_reconstruction_matches_oracle(recon_full, parity):
-    """13 views @448, width 1024, 16 heads x 64, 22 DINO + 24 frame + 24 global blocks, camera / depth / Gaussian heads, voxel fusion."""
+    """13 views @448, width 1024, 16 heads x 64, 22 DINO + 24 frame + 24 global blocks, camera / depth / Gaussian heads, voxel fusion.
+    Primary gate: against the oracle with the reference's GPU rounding points (`emulate_bf16`: bf16 Linear / SDPA / LayerScale outputs,
+    fp32 LayerNorm, bf16 DINO stream, fp32 aggregator stream, fp32 heads - oracle/recon.py docstring).  The oracle's backbone runs twice
+    (contract, then plain fp32 for the informational tap figures and the contract-vs-fp32 floor), its heads once, on the contract taps."""
+    import time
     ocfg, sd = recon_full
     model = _stitched(sd, {}, 1024)
     g = torch.Generator().manual_seed(52)
@@ -83,23 +104,38 @@ def test_full_size_reconstruction_matches_oracle(recon_full, parity):
     _, geo = eng.token_workspace(S, H, H)
     taps = [t.view(S, geo["Pp"], -1)[:, :geo["P"]].float().cpu() for t in geo["taps"]]
     with torch.no_grad():
+        t0 = time.time()
+        feat_c = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
+        ctaps = R.backbone(sd, feat_c, 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth, emulate_bf16=True)
+        t1 = time.time()
         feat = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1))
         otaps = R.backbone(sd, feat, 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth)
-        ora = R.recon_forward(sd, ocfg, feat, img)
-    tap_err = [_rel(t, o[0]) for t, o in zip(taps, otaps)]
+        t2 = time.time()
+        ora = R.recon_forward(sd, ocfg, feat_c, img, toks=ctaps)
+        t3 = time.time()
+    tap_c = [_rel(t, o[0]) for t, o in zip(taps, ctaps)]
+    tap_32 = [_rel(t, o[0]) for t, o in zip(taps, otaps)]
+    floor = [_rel(c[0], o[0]) for c, o in zip(ctaps, otaps)]
     e = dict(pose=_rel(eo.pred_pose_enc_list[-1], ora["pred_pose_enc_list"][-1]), depth=_rel(eo.depth_dict["depth"], ora["depth"]),
              depth_conf=_rel(dconf, ora["depth_conf"]), raw_gs=_rel(anchor, ora["raw_gs"][:, :, :83]), gs_conf=_rel(conf, ora["raw_gs"][:, :, 83]),
              c2w=_rel(eo.pred_context_pose["extrinsic"], ora["pred_context_pose"]["extrinsic"]),
              intrinsic=_rel(eo.pred_context_pose["intrinsic"], ora["pred_context_pose"]["intrinsic"]))
     U, Uo = eo.gaussians.means.shape[1], ora["gaussians"]["means"].shape[1]
-    parity("recon_full_size_C1024_H16_S13", taps=tap_err, voxels=U, voxels_oracle=Uo, **e)
-    print("full-size recon taps", [f"{t:.2e}" for t in tap_err], {k: f"{v:.2e}" for k, v in e.items()}, "voxels", U, "oracle", Uo)
+    parity("recon_full_size_C1024_H16_S13", taps_vs_contract=tap_c, taps_vs_fp32=tap_32, taps_contract_vs_fp32=floor, voxels=U, voxels_oracle=Uo,
+           oracle_seconds=dict(backbone_contract=t1 - t0, backbone_fp32=t2 - t1, heads=t3 - t2), **e)
+    print("full-size recon taps vs contract", [f"{t:.2e}" for t in tap_c], "vs fp32", [f"{t:.2e}" for t in tap_32], "contract vs fp32",
+          [f"{t:.2e}" for t in floor], {k: f"{v:.2e}" for k, v in e.items()}, "voxels", U, "oracle", Uo,
+          f"oracle s: {t1 - t0:.0f} + {t2 - t1:.0f} + {t3 - t2:.0f}")
     assert all(torch.isfinite(t).all() for t in taps)
-    # measured on MI355X: taps 9.2e-3 / 8.1e-3 / 7.7e-3 / 7.1e-3, pose 2.8e-3, depth 3.9e-3, depth_conf 1.7e-3, raw_gs 9.3e-3, gs_conf 1.4e-2,
-    # c2w 4.2e-3, intrinsic 3.7e-5, 1 302 628 voxels vs 1 321 831 (-1.5 %)
-    assert max(tap_err) < 1.8e-2 and e["pose"] < 5.6e-3 and e["depth"] < 7.8e-3 and e["depth_conf"] < 3.5e-3 and e["raw_gs"] < 1.9e-2
-    assert e["gs_conf"] < 2.8e-2 and e["c2w"] < 8.4e-3 and e["intrinsic"] < 1e-4
+    # gates at <= 2x the HIP-vs-contract figures measured on MI355X (profiles/r4/parity.json); round 3 measured against the fp32 oracle:
+    # taps 9.2e-3 / 8.1e-3 / 7.7e-3 / 7.1e-3, pose 2.8e-3, depth 3.9e-3, depth_conf 1.7e-3, raw_gs 9.3e-3, gs_conf 1.4e-2, c2w 4.2e-3
+    assert max(tap_c) < RECON_GATES["taps"] and max(tap_32) < 1.8e-2, (tap_c, tap_32)
+    for k in ("pose", "depth", "depth_conf", "raw_gs", "gs_conf", "c2w", "intrinsic"):
+        assert e[k] < RECON_GATES[k], (k, e[k])
     assert abs(U - Uo) <= 0.03 * Uo
+
+
+RECON_GATES = dict(taps=1.8e-2, pose=5.6e-3, depth=7.8e-3, depth_conf=3.5e-3, raw_gs=1.9e-2, gs_conf=2.8e-2, c2w=8.4e-3, intrinsic=1e-4)
 
 
 def test_config3_21_view_dit_forward_matches_oracle(hip_lib, parity):
@@ -148,14 +184,19 @@ def test_config3_21_view_reconstruction_layout_matches_oracle(hip_lib, parity):
     eo, anchor, conf, dconf = model.forward_with_latent(lat.cuda(), img.cuda(), train=True)
     torch.cuda.synchronize()
     with torch.no_grad():
-        feat = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1))
-        ora = R.recon_forward(sd, ocfg, feat, img)
-    e = dict(pose=_rel(eo.pred_pose_enc_list[-1], ora["pred_pose_enc_list"][-1]), depth=_rel(eo.depth_dict["depth"], ora["depth"]),
-             depth_conf=_rel(dconf, ora["depth_conf"]), raw_gs=_rel(anchor, ora["raw_gs"][:, :, :83]))
+        feat = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
+        ora = R.recon_forward(sd, ocfg, feat, img, emulate_bf16=True)                       # the reference's GPU rounding points, fp32 heads
+        dev = R.recon_forward(sd, ocfg, feat, img, dpt_bf16=True, toks=ora["taps"])         # + the HIP path's documented bf16 DPT heads
+    errs = lambda o: dict(pose=_rel(eo.pred_pose_enc_list[-1], o["pred_pose_enc_list"][-1]), depth=_rel(eo.depth_dict["depth"], o["depth"]),
+                          depth_conf=_rel(dconf, o["depth_conf"]), raw_gs=_rel(anchor, o["raw_gs"][:, :, :83]))
+    e, ed = errs(ora), errs(dev)
+    price = dict(depth=_rel(dev["depth"], ora["depth"]), raw_gs=_rel(dev["raw_gs"], ora["raw_gs"]))
     U, Uo = eo.gaussians.means.shape[1], ora["gaussians"]["means"].shape[1]
-    parity("recon_config3_S21_448_width128", voxels=U, voxels_oracle=Uo, **e)
-    print("config #3 recon layout (S=21 @448, width 128):", {k: f"{v:.2e}" for k, v in e.items()}, "voxels", U, "oracle", Uo)
-    assert e["pose"] < 9e-3 and e["depth"] < 7.4e-3 and e["depth_conf"] < 3.8e-3 and e["raw_gs"] < 1.65e-2   # measured 4.6e-3 / 3.7e-3 / 1.9e-3 / 8.2e-3
+    parity("recon_config3_S21_448_width128", voxels=U, voxels_oracle=Uo, vs_contract=e, vs_contract_with_bf16_dpt_heads=ed,
+           bf16_dpt_heads_move_the_oracle_by=price)
+    print("config #3 recon layout (S=21 @448, width 128): vs contract", {k: f"{v:.2e}" for k, v in e.items()}, "vs contract + bf16 DPT heads",
+          {k: f"{v:.2e}" for k, v in ed.items()}, "price of the bf16 heads", {k: f"{v:.2e}" for k, v in price.items()}, "voxels", U, "oracle", Uo)
+    assert e["pose"] < 9e-3 and e["depth"] < 7.4e-3 and e["depth_conf"] < 3.8e-3 and e["raw_gs"] < 1.65e-2   # round 3 vs fp32: 4.6e-3 / 3.7e-3 / 1.9e-3 / 8.2e-3
     assert abs(U - Uo) <= 0.03 * Uo      # measured -1.3 %
 
 

@@ -256,3 +256,30 @@ def test_load_peft_lora_folder_layout(tmp_path):
     import pytest
     with pytest.raises(KeyError):
         load_peft_lora(str(tmp_path), sd)
+
+
+def test_full_upstream_checkpoint_drops_first_k_dino_blocks_and_reindexes_all():
+    """convert_model_to_stitched_model (/root/reference/models/anysplat_stitched.py:158-165): a checkpoint with ALL DINO blocks loses
+    blocks [0, k) and block i becomes block i - k - for every block (a one-pass in-place rename collides at i - k == j)."""
+    from oracle import recon as R
+    from vist3a_amd.models.anysplat_stitched import AnySplatStitched, AnySplatWeights
+    from vist3a_amd.recon.engine import ReconCfg
+    kw = dict(C=64, heads=1, n_dino=22, depth=2, cam_heads=2, cam_trunk=1, features=32, oc=(16, 32, 64, 64))
+    ssd = R.make_recon_weights(R.ReconCfg(**kw), seed=1)
+    pe = "encoder.aggregator.patch_embed.blocks."
+    full = {}
+    for k, v in ssd.items():
+        if k.startswith(pe):
+            i, rest = k[len(pe):].split(".", 1)
+            full[f"{pe}{int(i) + 2}.{rest}"] = v
+            if int(i) < 2:
+                full[f"{pe}{i}.{rest}"] = torch.full_like(v, 7.0)
+        else:
+            full[k] = v
+    m = AnySplatStitched(AnySplatWeights(full, ReconCfg(**kw), n_total_dino_blocks=24), "enc_blocks_2", "cpu")
+    got = {k: v for k, v in m._sd.items() if k.startswith(pe)}
+    assert set(got) == {k for k in ssd if k.startswith(pe)}
+    assert all(torch.equal(got[k], ssd[k]) for k in got)
+    import pytest
+    with pytest.raises(ValueError):   # a checkpoint that is neither stitched (22) nor full (24)
+        AnySplatStitched(AnySplatWeights({k: v for k, v in full.items() if ".blocks.23." not in k}, ReconCfg(**kw), n_total_dino_blocks=24), "enc_blocks_2", "cpu")

@@ -59,6 +59,12 @@ DIT_SHAPES = [
     ("ffn1+gelu", 8192, 8960, 1536, dict(bias=True, act="gelu_tanh")),
     ("ffn2+gate+res", 8192, 1536, 8960, dict(bias=True, res="bf16", scale="batch", rpb=4096)),
     ("vT_proj", 1536, 8192, 1536, dict(bias=True, bias_row=True)),
+    # BASELINE config #4: Wan-14B (d = 5120 = 26.67 x 192, ffn 13824 = 72 x 192: ragged / multi-round tilings at M = 8192)
+    ("14b_attn_out+gate+res", 8192, 5120, 5120, dict(bias=True, res="bf16", scale="batch", rpb=4096)),
+    ("14b_qk_proj", 8192, 10240, 5120, dict(bias=True)),
+    ("14b_ffn1+gelu", 8192, 13824, 5120, dict(bias=True, act="gelu_tanh")),
+    ("14b_ffn2+gate+res", 8192, 5120, 13824, dict(bias=True, res="bf16", scale="batch", rpb=4096)),
+    ("14b_vT_proj", 5120, 8192, 5120, dict(bias=True, bias_row=True)),
 ]
 
 

@@ -115,3 +115,30 @@ def test_conf_mask_branch_golden():
     # the mask arithmetic itself, on the reference's confidences: index-exact
     q = torch.quantile(g["depth_conf"].flatten(0, 1), 0.1)
     assert torch.equal(q.reshape(1), g["quantile"]) and torch.equal(g["depth_conf"] > q, g["mask"].bool())
+
+
+def test_bf16_contract_modes_are_roundings_of_the_pinned_form():
+    """emulate_bf16 (CUDA-autocast rounding points in the backbone) and dpt_bf16 (the HIP path's bf16 DPT heads) are OFF by default -
+    the golden-pinned fp32 form above is what runs - and move the outputs by bf16-noise amounts only; precomputed taps are honoured."""
+    from vist3a_amd.recon.weights import round_aggregator_to_bf16
+    g = load_file(str(G / "recon_mh.safetensors"))
+    cfg = R.ReconCfg(**RECON_MH)
+    sd = round_aggregator_to_bf16(R.make_recon_weights(cfg, seed=43))
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    with torch.no_grad():
+        o32 = R.recon_forward(sd, cfg, g["latent"], g["image"])
+        oe = R.recon_forward(sd, cfg, g["latent"], g["image"], emulate_bf16=True)
+        od = R.recon_forward(sd, cfg, g["latent"], g["image"], emulate_bf16=True, dpt_bf16=True, toks=oe["taps"])
+        again = R.recon_forward(sd, cfg, g["latent"], g["image"])
+    assert not R._EMU and not R._DPT16
+    assert torch.equal(again["depth"], o32["depth"])                       # switches restored: the default is the fp32 form
+    t = [rel(a, b) for a, b in zip(oe["taps"], o32["taps"])]
+    assert all(5e-4 < x < 5e-2 for x in t), t
+    assert 1e-4 < rel(oe["depth"], o32["depth"]) < 3e-2
+    assert all(torch.equal(a, b) for a, b in zip(od["taps"], oe["taps"]))  # toks= skipped the backbone
+    assert torch.equal(od["pred_pose_enc_list"][-1], oe["pred_pose_enc_list"][-1])   # camera head stays fp32 under dpt_bf16
+    assert 1e-4 < rel(od["depth"], oe["depth"]) < 3e-2                      # the bf16 DPT heads move the depth by bf16 noise
+    # the flash contract against exact softmax attention
+    q, k, v = (torch.randn(1, 2, 70, 64).to(torch.bfloat16).float() for _ in range(3))
+    a, b = R.attention_bf16p(q, k, v, block_elems=70 * 64), torch.nn.functional.scaled_dot_product_attention(q, k, v)
+    assert 1e-5 < rel(a, b) < 5e-3

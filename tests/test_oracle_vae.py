@@ -67,3 +67,27 @@ def test_encoder_plan_causality_and_posterior():
     params = torch.cat([torch.full((1, 2, 1, 1, 1), 3.0), torch.tensor([0.0, 40.0]).view(1, 2, 1, 1, 1)], 1)
     z = OV.posterior_sample(params, torch.ones(1, 2, 1, 1, 1))
     assert torch.allclose(z.flatten(), torch.tensor([3.0 + 1.0, 3.0 + float(torch.exp(torch.tensor(10.0)))]))  # logvar clamped to 20
+
+
+def test_bf16_contract_mode_is_a_rounding_of_the_pinned_form():
+    """emulate_bf16 = the same arithmetic with CUDA autocast's bf16 rounding points: off by default (the golden-pinned form is
+    untouched), within bf16 noise of the fp32 form, every conv input / output bf16-representable, and the global switch restored."""
+    g = load_file(str(GOLD))
+    cfg = OV.WanVAEConfig(base_dim=16)
+    sd = OV.make_weights(cfg, seed=11)
+    ref = OV.decode(sd, cfg, g["z"])
+    emu = OV.decode(sd, cfg, g["z"], emulate_bf16=True)
+    assert not OV._EMU and torch.equal(OV.decode(sd, cfg, g["z"]), ref)
+    rel = ((emu - ref).norm() / ref.norm()).item()
+    assert 1e-3 < rel < 4e-2, rel                                    # ~35 bf16-rounded conv layers
+    assert torch.equal(emu, emu.to(torch.bfloat16).float())          # the output of the last conv is a bf16 value (clamp keeps it one)
+    esd = OV.make_encoder_weights(cfg, seed=12)
+    ge = load_file(str(ENC_GOLD))
+    e32, e16 = OV.encode(esd, cfg, ge["x"]), OV.encode(esd, cfg, ge["x"], emulate_bf16=True)
+    rel = ((e16 - e32).norm() / e32.norm()).item()
+    assert 1e-3 < rel < 4e-2, rel
+    # flash contract: bf16 probabilities, fp32 row sum of the unrounded ones
+    q, k, v = (torch.randn(2, 1, 50, 16).to(torch.bfloat16).float() for _ in range(3))
+    a = OV.sdpa_bf16p(q, k, v)
+    b = torch.nn.functional.scaled_dot_product_attention(q, k, v)
+    assert 1e-5 < ((a - b).norm() / b.norm()).item() < 5e-3

@@ -36,11 +36,13 @@ class AnySplatStitched(torch.nn.Module):
         if model.n_total_dino_blocks is not None and len(present) == model.n_total_dino_blocks:
             # full upstream checkpoint: delete the first k blocks and re-index, as convert_model_to_stitched_model (:158-165)
             k = self.stitched_layer_index
+            moved = {}   # two passes: renaming in place would let "blocks.10." land on "blocks.8." before the old "blocks.8." has moved
             for key in [q for q in sd if q.startswith(pe)]:
                 i = int(key[len(pe):].split(".")[0])
                 v = sd.pop(key)
                 if i >= k:
-                    sd[pe + str(i - k) + key[len(pe) + len(str(i)):]] = v
+                    moved[pe + str(i - k) + key[len(pe) + len(str(i)):]] = v
+            sd.update(moved)
             present = present[k:]
         if len(present) != cfg.n_dino:
             raise ValueError(f"state dict holds {len(present)} DINO blocks after stitching, config expects {cfg.n_dino}")

@@ -22,9 +22,22 @@ def load_feedforward_model(args, device) -> AnySplatWeights:
     cfg = ReconCfg()
     path = getattr(args, "anysplat_weights", None)
     if path:
+        # a local .safetensors, or a hub-snapshot folder (`model.safetensors` + `config.json`, the layout AnySplat.from_pretrained /
+        # PyTorchModelHubMixin reads, utils/utils_for_thirdparty.py:14-25).  The upstream config.json does not describe the VGGT
+        # backbone (its width / depth are constants of the code); an optional "recon_cfg" object there overrides ReconCfg fields
+        # (reduced-size checkpoints for tests).  The checkpoint is the FULL upstream model: all DINO blocks, the first k are dropped
+        # by AnySplatStitched exactly as convert_model_to_stitched_model does (anysplat_stitched.py:158-165).
+        import json
+        import os
         from safetensors.torch import load_file
+        if os.path.isdir(path):
+            cj = os.path.join(path, "config.json")
+            if os.path.exists(cj):
+                cfg = ReconCfg(**json.load(open(cj)).get("recon_cfg", {}))
+            path = os.path.join(path, "model.safetensors")
         sd = load_file(path)
-        return AnySplatWeights(sd, cfg, n_total_dino_blocks=24)
+        k = int(args.stitching_layer_location.split("_")[-1])
+        return AnySplatWeights(sd, cfg, n_total_dino_blocks=cfg.n_dino + k)
     if getattr(args, "checkpoint_path", None) == "synthetic":
         return AnySplatWeights(round_aggregator_to_bf16(random_recon_state_dict(cfg, seed=2, device=str(device))), cfg)
     raise FileNotFoundError("AnySplat weights: pass --anysplat_weights <local .safetensors> (the HF hub id 'lhjiang/anysplat' the "
@@ -38,9 +51,16 @@ def load_vae(args, device):
         raise NotImplementedError(f"Video diffusion model {args.video_model} is not implemented.")
     cfg = WanVAEConfig()
     model_dir = getattr(args, "model_id", None)
+    import json
     import os
     if model_dir and os.path.isdir(os.path.join(model_dir, "vae")):
         from safetensors.torch import load_file
+        cj = os.path.join(model_dir, "vae", "config.json")   # AutoencoderKLWan's registered config (utils/wan_utils.py:904-923)
+        if os.path.exists(cj):
+            c = json.load(open(cj))
+            if c.get("attn_scales"):
+                raise NotImplementedError("Wan VAE with attn_scales (attention inside the up blocks) is not implemented")
+            cfg = WanVAEConfig(**{k: c[k] for k in ("base_dim", "z_dim", "dim_mult", "num_res_blocks", "temperal_downsample") if k in c})
         sd = load_file(os.path.join(model_dir, "vae", "diffusion_pytorch_model.safetensors"))
     elif getattr(args, "checkpoint_path", None) == "synthetic":
         sd = random_vae_decoder_state_dict(cfg, 1, str(device))

@@ -50,6 +50,29 @@ def random_dit_state_dict(cfg: WanDiTConfig, seed: int = 0, device="cpu", dtype=
     return sd
 
 
+def load_dit_config(model_dir: str, default: WanDiTConfig) -> WanDiTConfig:
+    """`<model_dir>/transformer/config.json` the way diffusers' `from_pretrained` reads it (WanTransformer3DModel's registered config:
+    patch_size, num_attention_heads, attention_head_dim, in/out_channels, text_dim, freq_dim, ffn_dim, num_layers, eps,
+    rope_max_seq_len); `default` when the folder has no config.  Options this path does not implement raise instead of being ignored."""
+    p = Path(model_dir)
+    if (p / "transformer").is_dir():
+        p = p / "transformer"
+    f = p / "config.json"
+    if not f.exists():
+        return default
+    c = json.loads(f.read_text())
+    if c.get("image_dim") is not None or c.get("added_kv_proj_dim") is not None:
+        raise NotImplementedError("image-to-video Wan transformers (image_dim / added_kv_proj_dim) are outside the text->3DGS path")
+    if c.get("qk_norm", "rms_norm_across_heads") != "rms_norm_across_heads" or not c.get("cross_attn_norm", True):
+        raise NotImplementedError("only qk_norm='rms_norm_across_heads' with cross_attn_norm=True (Wan 2.1 T2V) is implemented")
+    names = ("num_attention_heads", "attention_head_dim", "in_channels", "out_channels", "text_dim", "freq_dim", "ffn_dim", "num_layers",
+             "eps", "rope_max_seq_len")
+    kw = {k: c[k] for k in names if k in c}
+    if "patch_size" in c:
+        kw["patch_size"] = tuple(c["patch_size"])
+    return WanDiTConfig(**kw)
+
+
 def load_dit_state_dict(model_dir: str) -> Dict[str, torch.Tensor]:
     """Read a diffusers `transformer/` folder (sharded or single .safetensors)."""
     from safetensors.torch import load_file
