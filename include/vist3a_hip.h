@@ -127,8 +127,18 @@ typedef struct {
   int act, flags, tile;
   const void* residual2; int ldr2; int res_row_mod;
   int out_row_group, out_row_skip, out_row_off;   /* as in v3a_gemm_args */
+  /* Optional second packing of the same weights for the HALO-TILE kernel (csrc/conv_halo.hip): 3x3 spatial taps, kT = halo_kT in
+   * {1, 3} (causal in time: pT = kT - 1), stride 1, zero padding 1, Cin % 48 == 0, Cout % 96 == 0, oH % 16 == 0, oW % 32 == 0.
+   * The input patch of a 16 x 32-pixel output tile is staged once in LDS and the nine spatial taps are read as shifted views of it
+   * (the Wan VAE decoder's wide-image layers, /root/reference/utils/wan_utils.py:96-147, 202-330, 333-425).
+   * Layout: w_halo[Cout/96][kT][Cin/48][9 = dh*3+dw][96 rows n][48 k] bf16, where the six 16-byte chunks of a row are stored
+   * rotated: logical chunk c of row n sits at position (c + 3*((n >> 3) & 1)) % 6 (the kernel's LDS bank layout; the slab is
+   * copied to LDS verbatim).  NULL = implicit-GEMM path only.  v3a_conv_bf16 takes the halo kernel when w_halo is set, the layer
+   * has this form, tile < 0 and v3a_conv_halo_tiles(args) >= 512; tile == -2 forces it, tile == -3 forbids it. */
+  const void* w_halo; int halo_kT;
 } v3a_conv_args;
 int v3a_conv_bf16(const v3a_conv_args* args, void* stream);
+long v3a_conv_halo_tiles(const v3a_conv_args* args);   /* workgroups the halo kernel would launch; 0 = layer not of its form */
 
 /* ------------------------------------------------------------------------------------------------
  * Flash attention forward (non-causal, no mask, no dropout), bf16 in/out, fp32 softmax.

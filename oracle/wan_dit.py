@@ -177,8 +177,18 @@ def attention(q, k, v, heads, emu, flash=False, key_bias=None):
     kh = k.view(B, -1, heads, hd).transpose(1, 2)
     vh = v.view(B, -1, heads, hd).transpose(1, 2)
     if flash:
-        kb = None if key_bias is None else key_bias[:, None, :]
-        o = attention_flash_emulated(_r(qh, True), _r(kh, True), _r(vh, True), hd ** -0.5, key_bias=kb)
+        # one batch item and <= ~16 MB of scores per call of the tile loop (12 heads x 4096 queries x 64 keys: the Wan-1.3B slab, measured
+        # fastest on the host; the Wan-14B CFG pair would otherwise stream 84 MB per elementwise op)
+        qh, kh, vh = _r(qh, True), _r(kh, True), _r(vh, True)
+        o = torch.empty(B, heads, Nq, hd)
+        QC = Nq if Nq <= 4096 else 4096               # a multiple of the 32-row wave the deferred-rescale decision is taken over
+        HG = max(1, min(heads, (1 << 22) // (QC * 64)))
+        for b in range(B):
+            kb = None if key_bias is None else key_bias[b][None, :]
+            for h0 in range(0, heads, HG):
+                for q0 in range(0, Nq, QC):
+                    o[b, h0:h0 + HG, q0:q0 + QC] = attention_flash_emulated(qh[b, h0:h0 + HG, q0:q0 + QC], kh[b, h0:h0 + HG], vh[b, h0:h0 + HG],
+                                                                             hd ** -0.5, key_bias=kb)
     else:
         bias = None if key_bias is None else key_bias[:, None, None, :]
         o = F.scaled_dot_product_attention(_r(qh, emu), _r(kh, emu), _r(vh, emu), attn_mask=bias)
@@ -219,7 +229,13 @@ def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gem
     k = apply_rope(k.view(B, N, H, -1).transpose(1, 2), freqs).transpose(1, 2).reshape(B, N, d)
     if fp8_attn:   # MI355X fp8 self-attention mode (see attention_fp8_emulated below): bf16 q, k, v -> e4m3, unit scales
         hs = lambda t: _r(t, True).view(B, N, H, -1).transpose(1, 2)
-        ao = attention_fp8_emulated(hs(q), hs(k), hs(v), (d // H) ** -0.5).transpose(1, 2).reshape(B, N, d)
+        q8, k8, v8 = hs(q), hs(k), hs(v)
+        ao = torch.empty(B, H, N, d // H)
+        HG = max(1, min(H, (1 << 22) // (N * 64)))    # <= ~16 MB of scores per call (see attention())
+        for bi in range(B):
+            for h0 in range(0, H, HG):
+                ao[bi, h0:h0 + HG] = attention_fp8_emulated(q8[bi, h0:h0 + HG], k8[bi, h0:h0 + HG], v8[bi, h0:h0 + HG], (d // H) ** -0.5)
+        ao = ao.transpose(1, 2).reshape(B, N, d)
         a = _lin(_r(ao, emu), sd, p + "attn1.to_out.0", emu, g8)
     else:
         a = _lin(attention(q, k, v, H, emu, flash), sd, p + "attn1.to_out.0", emu, g8)

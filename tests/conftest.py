@@ -11,14 +11,6 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with `-m gpu`)")
-    # pytest.ini runs the suite on 4 xdist workers (the wall time of `-m gpu` is the CPU oracle at production size: ~10 min serial).
-    # Each worker's torch CPU pool gets half the host's threads: at most two or three oracle-heavy tests overlap at any time.
-    if os.environ.get("PYTEST_XDIST_WORKER"):
-        try:
-            import torch
-            torch.set_num_threads(max(4, (os.cpu_count() or 8) // 2))
-        except Exception:  # noqa: BLE001
-            pass
 
 
 def _has_gpu() -> bool:

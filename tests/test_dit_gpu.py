@@ -439,9 +439,9 @@ def test_time_tables_bit_identical_at_production_width(hip_lib, width):
 
 def test_config4_wan14b_two_blocks_at_4096_tokens_matches_oracle(hip_lib, parity):
     """BASELINE config #4 AT SIZE: Wan-14B width (40 heads x 128 = 5120, FFN 13824), the CFG pair (B = 2) of a 13-view scene
-    (N = 4096 tokens, M = 8192 GEMM rows: the ragged 5120 / 13824 tilings at their real M), two blocks, 512-row zero-padded prompts -
+    (N = 4096 tokens, M = 8192 GEMM rows: the ragged 5120 / 13824 tilings at their real M), 512-row zero-padded prompts - two blocks
     in bf16 against the oracle with the kernel contracts emulated (bf16 rounding points, bf16-P flash tiles, merged padding key),
-    and in the config's fp8-attention mode against the oracle with the e4m3 rounding points."""
+    and one block in the config's fp8-attention mode against the oracle with the e4m3 rounding points."""
     import time
     from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
     kw = dict(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=2, text_dim=512, freq_dim=256)
@@ -455,17 +455,18 @@ def test_config4_wan14b_two_blocks_at_4096_tokens_matches_oracle(hip_lib, parity
     text[1, 80:] = 0
     t = torch.tensor([611, 611])
     out16 = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
+    out16_1 = model(lat.cuda(), t.cuda(), text.cuda(), num_layers=1)[0].float().cpu()
     model.attn_dtype = "fp8"
-    out8 = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
+    out8 = model(lat.cuda(), t.cuda(), text.cuda(), num_layers=1)[0].float().cpu()    # the fp8 mode on ONE block (half the oracle time)
     model.attn_dtype = "bf16"
     torch.cuda.synchronize()
     t0 = time.time()
     with torch.no_grad():
         ref16 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True)
         t1 = time.time()
-        ref8 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, flash=True, merge_padding=True)
+        ref8 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, flash=True, merge_padding=True, num_layers=1)
     t2 = time.time()
-    r16, r8, shift = _rel(out16, ref16), _rel(out8, ref8), _rel(out8, out16)
+    r16, r8, shift = _rel(out16, ref16), _rel(out8, ref8), _rel(out8, out16_1)
     parity("dit_config4_14B_N4096_B2_two_blocks", rel_bf16_vs_contract_oracle=r16, rel_fp8_attention_vs_e4m3_oracle=r8,
            fp8_attention_mode_vs_bf16_mode=shift, oracle_seconds=[t1 - t0, t2 - t1])
     print(f"config #4 at size (14B width, N=4096, B=2, 2 blocks): bf16 vs contract oracle {r16:.2e}; fp8 attention vs e4m3 oracle {r8:.2e}; "

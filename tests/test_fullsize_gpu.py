@@ -86,8 +86,9 @@ def _stitched(sd, rcfg_kw, C, res=512):
 def test_full_size_reconstruction_matches_oracle(recon_full, parity):
     """13 views @448, width 1024, 16 heads x 64, 22 DINO + 24 frame + 24 global blocks, camera / depth / Gaussian heads, voxel fusion.
     Primary gate: against the oracle with the reference's GPU rounding points (`emulate_bf16`: bf16 Linear / SDPA / LayerScale outputs,
-    fp32 LayerNorm, bf16 DINO stream, fp32 aggregator stream, fp32 heads - oracle/recon.py docstring).  The oracle's backbone runs twice
-    (contract, then plain fp32 for the informational tap figures and the contract-vs-fp32 floor), its heads once, on the contract taps."""
+    fp32 LayerNorm, bf16 DINO stream, fp32 aggregator stream, fp32 heads - oracle/recon.py docstring).  One oracle pass (backbone in
+    contract mode, fp32 heads on its taps); the figures against the plain fp32 oracle (round 3: taps 9.2e-3 .. 7.1e-3) are informational and
+    taken in the 21-view layout test below, where all three oracle forms run in a minute."""
     import time
     ocfg, sd = recon_full
     model = _stitched(sd, {}, 1024)
@@ -108,28 +109,22 @@ def test_full_size_reconstruction_matches_oracle(recon_full, parity):
         feat_c = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
         ctaps = R.backbone(sd, feat_c, 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth, emulate_bf16=True)
         t1 = time.time()
-        feat = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1))
-        otaps = R.backbone(sd, feat, 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth)
-        t2 = time.time()
         ora = R.recon_forward(sd, ocfg, feat_c, img, toks=ctaps)
-        t3 = time.time()
+        t2 = time.time()
     tap_c = [_rel(t, o[0]) for t, o in zip(taps, ctaps)]
-    tap_32 = [_rel(t, o[0]) for t, o in zip(taps, otaps)]
-    floor = [_rel(c[0], o[0]) for c, o in zip(ctaps, otaps)]
     e = dict(pose=_rel(eo.pred_pose_enc_list[-1], ora["pred_pose_enc_list"][-1]), depth=_rel(eo.depth_dict["depth"], ora["depth"]),
              depth_conf=_rel(dconf, ora["depth_conf"]), raw_gs=_rel(anchor, ora["raw_gs"][:, :, :83]), gs_conf=_rel(conf, ora["raw_gs"][:, :, 83]),
              c2w=_rel(eo.pred_context_pose["extrinsic"], ora["pred_context_pose"]["extrinsic"]),
              intrinsic=_rel(eo.pred_context_pose["intrinsic"], ora["pred_context_pose"]["intrinsic"]))
     U, Uo = eo.gaussians.means.shape[1], ora["gaussians"]["means"].shape[1]
-    parity("recon_full_size_C1024_H16_S13", taps_vs_contract=tap_c, taps_vs_fp32=tap_32, taps_contract_vs_fp32=floor, voxels=U, voxels_oracle=Uo,
-           oracle_seconds=dict(backbone_contract=t1 - t0, backbone_fp32=t2 - t1, heads=t3 - t2), **e)
-    print("full-size recon taps vs contract", [f"{t:.2e}" for t in tap_c], "vs fp32", [f"{t:.2e}" for t in tap_32], "contract vs fp32",
-          [f"{t:.2e}" for t in floor], {k: f"{v:.2e}" for k, v in e.items()}, "voxels", U, "oracle", Uo,
-          f"oracle s: {t1 - t0:.0f} + {t2 - t1:.0f} + {t3 - t2:.0f}")
+    parity("recon_full_size_C1024_H16_S13", taps_vs_contract=tap_c, voxels=U, voxels_oracle=Uo,
+           oracle_seconds=dict(backbone_contract=t1 - t0, heads=t2 - t1), **e)
+    print("full-size recon taps vs contract", [f"{t:.2e}" for t in tap_c], {k: f"{v:.2e}" for k, v in e.items()}, "voxels", U, "oracle", Uo,
+          f"oracle s: {t1 - t0:.0f} + {t2 - t1:.0f}")
     assert all(torch.isfinite(t).all() for t in taps)
     # gates at <= 2x the HIP-vs-contract figures measured on MI355X (profiles/r4/parity.json); round 3 measured against the fp32 oracle:
     # taps 9.2e-3 / 8.1e-3 / 7.7e-3 / 7.1e-3, pose 2.8e-3, depth 3.9e-3, depth_conf 1.7e-3, raw_gs 9.3e-3, gs_conf 1.4e-2, c2w 4.2e-3
-    assert max(tap_c) < RECON_GATES["taps"] and max(tap_32) < 1.8e-2, (tap_c, tap_32)
+    assert max(tap_c) < RECON_GATES["taps"], tap_c
     for k in ("pose", "depth", "depth_conf", "raw_gs", "gs_conf", "c2w", "intrinsic"):
         assert e[k] < RECON_GATES[k], (k, e[k])
     assert abs(U - Uo) <= 0.03 * Uo
@@ -157,12 +152,11 @@ def test_config3_21_view_dit_forward_matches_oracle(hip_lib, parity):
     torch.cuda.synchronize()
     with torch.no_grad():
         ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True)
-        ref32 = O.dit_forward(sd, ocfg, lat.float(), t, text)
-    r, r32 = _rel(out, ref), _rel(out, ref32)
-    parity("dit_config3_N6144_two_blocks", rel_vs_contract_oracle=r, rel_vs_fp32_oracle=r32)
-    print(f"config #3 DiT (N=6144, 2 blocks): rel vs contract oracle {r:.2e}, vs fp32 oracle {r32:.2e}")
+    r = _rel(out, ref)
+    parity("dit_config3_N6144_two_blocks", rel_vs_contract_oracle=r)
+    print(f"config #3 DiT (N=6144, 2 blocks): rel vs contract oracle {r:.2e}")
     assert out.shape == lat.shape and torch.isfinite(out).all()
-    assert r < 5.2e-3 and r32 < 1e-2, (r, r32)     # measured 2.6e-3 / 5.0e-3
+    assert r < 5.2e-3, r     # measured 2.6e-3 (round 3 also ran the plain fp32 oracle: 5.0e-3, profiles/r3/parity.json)
 
 
 RECON_MH = dict(C=128, heads=2, n_dino=22, depth=24, cam_heads=4, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
@@ -187,15 +181,23 @@ def test_config3_21_view_reconstruction_layout_matches_oracle(hip_lib, parity):
         feat = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
         ora = R.recon_forward(sd, ocfg, feat, img, emulate_bf16=True)                       # the reference's GPU rounding points, fp32 heads
         dev = R.recon_forward(sd, ocfg, feat, img, dpt_bf16=True, toks=ora["taps"])         # + the HIP path's documented bf16 DPT heads
+        o32 = R.recon_forward(sd, ocfg, R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1)), img)   # plain fp32 (informational)
     errs = lambda o: dict(pose=_rel(eo.pred_pose_enc_list[-1], o["pred_pose_enc_list"][-1]), depth=_rel(eo.depth_dict["depth"], o["depth"]),
                           depth_conf=_rel(dconf, o["depth_conf"]), raw_gs=_rel(anchor, o["raw_gs"][:, :, :83]))
-    e, ed = errs(ora), errs(dev)
+    e, ed, e32 = errs(ora), errs(dev), errs(o32)
+    eng = model.stitched_3d_model.engine()
+    _, geo = eng.token_workspace(S, H, H)
+    taps = [t_.view(S, geo["Pp"], -1)[:, :geo["P"]].float().cpu() for t_ in geo["taps"]]
+    tap_c, tap_32 = [_rel(a, c[0]) for a, c in zip(taps, ora["taps"])], [_rel(a, c[0]) for a, c in zip(taps, o32["taps"])]
+    floor = [_rel(c[0], o[0]) for c, o in zip(ora["taps"], o32["taps"])]
     price = dict(depth=_rel(dev["depth"], ora["depth"]), raw_gs=_rel(dev["raw_gs"], ora["raw_gs"]))
     U, Uo = eo.gaussians.means.shape[1], ora["gaussians"]["means"].shape[1]
-    parity("recon_config3_S21_448_width128", voxels=U, voxels_oracle=Uo, vs_contract=e, vs_contract_with_bf16_dpt_heads=ed,
-           bf16_dpt_heads_move_the_oracle_by=price)
+    parity("recon_config3_S21_448_width128", voxels=U, voxels_oracle=Uo, vs_contract=e, vs_contract_with_bf16_dpt_heads=ed, vs_fp32=e32,
+           bf16_dpt_heads_move_the_oracle_by=price, taps_vs_contract=tap_c, taps_vs_fp32=tap_32, taps_contract_vs_fp32=floor)
     print("config #3 recon layout (S=21 @448, width 128): vs contract", {k: f"{v:.2e}" for k, v in e.items()}, "vs contract + bf16 DPT heads",
-          {k: f"{v:.2e}" for k, v in ed.items()}, "price of the bf16 heads", {k: f"{v:.2e}" for k, v in price.items()}, "voxels", U, "oracle", Uo)
+          {k: f"{v:.2e}" for k, v in ed.items()}, "price of the bf16 heads", {k: f"{v:.2e}" for k, v in price.items()}, "vs fp32", {k: f"{v:.2e}" for k, v in e32.items()},
+          "taps vs contract", [f"{x:.2e}" for x in tap_c], "vs fp32", [f"{x:.2e}" for x in tap_32], "contract vs fp32", [f"{x:.2e}" for x in floor],
+          "voxels", U, "oracle", Uo)
     assert e["pose"] < 9e-3 and e["depth"] < 7.4e-3 and e["depth_conf"] < 3.8e-3 and e["raw_gs"] < 1.65e-2   # round 3 vs fp32: 4.6e-3 / 3.7e-3 / 1.9e-3 / 8.2e-3
     assert abs(U - Uo) <= 0.03 * Uo      # measured -1.3 %
 

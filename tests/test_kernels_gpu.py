@@ -384,6 +384,71 @@ def test_conv_variants_match_torch_conv3d(hip_lib, parity, case):
         assert (y[..., Cout:].float() - res[..., Cout:].float()).abs().max() == 0
 
 
+HALO_CASES = [
+    # name, Cin, Cout, kT, T, H, W (output extent), ups2, act / residual variants follow the VAE decoder's layers
+    ("halo_causal3x3x3_96", 96, 96, 3, 4, 32, 64, False),        # the 512^2 stage's layer at a small extent: all three dt cases (t = 0, 1, >= 2)
+    ("halo_causal3x3x3_192", 192, 192, 3, 3, 32, 32, False),     # two N tiles, four channel chunks
+    ("halo_ups2_conv3x3_192_96", 192, 96, 1, 3, 64, 64, True),   # WanResample: nearest-exact 2x + Conv2d, stored input 32 x 32
+    ("halo_conv3x3_384_192", 384, 192, 1, 2, 16, 32, True),      # single tile rows / columns: every halo edge is an image edge
+    ("halo_one_frame_96", 96, 96, 3, 1, 16, 32, False),          # T = 1: only dt = 2 exists (one step per chunk)
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
+def test_conv_halo_tile_kernel_matches_torch_and_implicit_gemm(hip_lib, parity, case):
+    """csrc/conv_halo.hip (input patch staged once in LDS, nine taps as shifted views) forced with tile=-2: against torch conv3d in fp32 on
+    the same bf16 operands (same bar as the implicit GEMM), against the implicit-GEMM kernel (tile=-3: differs only in fp32 summation
+    order), with bias + residual fused, and run to run."""
+    from vist3a_amd import ops
+    F = torch.nn.functional
+    name, Cin, Cout, kT, T, H, W, ups2 = case
+    g = torch.Generator(device=dev).manual_seed(31)
+    w = torch.randn(Cout, Cin, kT, 3, 3, device=dev, generator=g) / math.sqrt(Cin * kT * 9)
+    b = torch.randn(Cout, device=dev, generator=g)
+    sh, sw = (H // 2, W // 2) if ups2 else (H, W)
+    x = torch.randn(1, Cin, T, sh, sw, device=dev, generator=g).to(bf16)
+    cw = ops.ConvWeight(w.to(bf16), b)
+    assert cw.w_halo is not None
+    xcl = x[0].permute(1, 2, 3, 0).contiguous()
+    xin = x.float()
+    if ups2:
+        xin = F.interpolate(xin.transpose(1, 2).reshape(T, Cin, sh, sw), scale_factor=2.0, mode="nearest-exact").view(1, T, Cin, H, W).transpose(1, 2)
+    ref = F.conv3d(F.pad(xin, (1, 1, 1, 1, kT - 1, 0)), w.to(bf16).float(), b)
+    res = torch.randn(T, H, W, Cout, device=dev, generator=g).to(bf16)
+    pad = (kT - 1, 1, 1)
+    y = ops.conv(xcl, cw, pad=pad, ups2=ups2, residual=res, tile=-2)
+    y2 = ops.conv(xcl, cw, pad=pad, ups2=ups2, residual=res, tile=-2)
+    yi = ops.conv(xcl, cw, pad=pad, ups2=ups2, residual=res, tile=-3)
+    torch.cuda.synchronize()
+    refcl = (ref[0].permute(1, 2, 3, 0).to(bf16).float() + res.float()).to(bf16)
+    r, ri = relerr(y, refcl), relerr(y, yi)
+    parity("conv_halo", name=name, rel_vs_fp32=r, rel_vs_implicit_gemm=ri)
+    assert tuple(y.shape) == (T, H, W, Cout) and torch.equal(y, y2)
+    assert r < 1.5e-4 and ri < 1.5e-4, (name, r, ri)
+    # SiLU-free activation path of the epilogue + no residual (conv1 of a residual block feeds rownorm, conv_out has neither)
+    y3 = ops.conv(xcl, cw, pad=pad, ups2=ups2, tile=-2)
+    r3 = relerr(y3, ref[0].permute(1, 2, 3, 0).to(bf16))
+    assert r3 < 1.5e-4, (name, r3)
+
+
+def test_conv_halo_dispatch_rules(hip_lib):
+    """v3a_conv_bf16 takes the halo kernel only for layers of its form that fill the chip (>= 512 tiles), tile=-3 forbids it, tile=-2 on a
+    layer that is not of its form is an error, and a weight without the second packing never takes it."""
+    import ctypes as C
+    from vist3a_amd import lib as L, ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    w = torch.randn(96, 96, 3, 3, 3, device=dev, generator=g) * 0.05
+    cw = ops.ConvWeight(w.to(bf16), None)
+    x = torch.randn(2, 20, 36, 96, device=dev, generator=g).to(bf16)     # 20 x 36: not a multiple of 16 x 32
+    with pytest.raises(RuntimeError):
+        ops.conv(x, cw, pad=(2, 1, 1), tile=-2)
+    ops.conv(x, cw, pad=(2, 1, 1))                                          # falls back to the implicit GEMM
+    w5 = torch.randn(96, 96, 1, 5, 5, device=dev, generator=g) * 0.05
+    assert ops.ConvWeight(w5.to(bf16), None).w_halo is None
+    w64 = torch.randn(64, 96, 1, 3, 3, device=dev, generator=g) * 0.05
+    assert ops.ConvWeight(w64.to(bf16), None).w_halo is None
+
+
 def test_conv_stride2_trailing_zero_pad_only(hip_lib, parity):
     """WanResample downsample2d: ZeroPad2d((0,1,0,1)) + stride-2 conv = out_size override, taps past the edge read the zero page."""
     from vist3a_amd import ops

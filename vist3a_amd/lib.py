@@ -49,6 +49,7 @@ class ConvArgs(C.Structure):
         ("act", C.c_int), ("flags", C.c_int), ("tile", C.c_int),
         ("residual2", C.c_void_p), ("ldr2", C.c_int), ("res_row_mod", C.c_int),
         ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
+        ("w_halo", C.c_void_p), ("halo_kT", C.c_int),
     ]
 
 
@@ -174,6 +175,7 @@ SYMBOLS = {
     "v3a_gemm_pick_tile": (C.c_int, [C.c_int, C.c_int]),
     "v3a_gemm_tile_name": (C.c_char_p, [C.c_int]),
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "v3a_conv_halo_tiles": (C.c_long, [C.POINTER(ConvArgs)]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "v3a_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "v3a_unipc_cfg_step": (C.c_int, [C.POINTER(UniPCStepArgs), C.c_void_p]),

@@ -252,6 +252,16 @@ class ConvWeight:
             b[:Cout] = bias.detach().float().cpu()
         self.bias = b.to(device)
         self.has_bias = bias is not None
+        # second packing for the halo-tile kernel (csrc/conv_halo.hip; layout documented at v3a_conv_args.w_halo):
+        # [Cout/96][kT][Cin/48][9][96][48], the six 16-byte chunks of row n rotated by 3 * ((n >> 3) & 1)
+        self.w_halo = None
+        if kH == 3 and kW == 3 and kT in (1, 3) and self.CinP % 48 == 0 and self.CoutP % 96 == 0:
+            nN, nC = self.CoutP // 96, self.CinP // 48
+            h = wp.reshape(nN, 96, kT, 9, nC, 6, 8).permute(0, 2, 4, 3, 1, 5, 6).contiguous()   # [nN, kT, nC, 9, 96, 6 chunks, 8]
+            rot = 3 * ((torch.arange(96) >> 3) & 1)
+            src = (torch.arange(6)[None, :] - rot[:, None]) % 6                                  # position s of row n holds chunk (s - rot) % 6
+            h = torch.gather(h, 5, src.view(1, 1, 1, 1, 96, 6, 1).expand(nN, kT, nC, 9, 96, 6, 8))
+            self.w_halo = h.to(device=device, dtype=bf16).contiguous()
 
 
 def conv(
@@ -263,7 +273,9 @@ def conv(
 ) -> torch.Tensor:
     """x: channels-last [T,H,W,CinP] bf16 contiguous -> out [oT,oH,oW,CoutP].  pad = LEADING pad per dim.  Spatial
     dims follow PyTorch's symmetric-pad formula; the temporal dim is causal (all padding leading) when
-    pad_T == k_T - 1 and symmetric otherwise.  `out_size` overrides."""
+    pad_T == k_T - 1 and symmetric otherwise.  `out_size` overrides.
+    tile: -1 = automatic (the halo-tile kernel for wide 3x3(x3) layers, else the implicit GEMM with a heuristic tile), >= 0 = that
+    implicit-GEMM tile, -2 = force the halo-tile kernel (error if the layer is not of its form), -3 = never the halo-tile kernel."""
     if x.dim() != 4 or not x.is_contiguous() or x.dtype != bf16 or not x.is_cuda:
         raise ValueError("x must be a contiguous device bf16 tensor [T,H,W,C]")
     T, H, W, Cin = x.shape
@@ -301,6 +313,7 @@ def conv(
         int(ups2), int(replicate), o2.stride(0), ldr, act, flags, tile,
         _ptr(residual2), residual2.view(-1, residual2.shape[-1]).stride(0) if residual2 is not None else 0, res_row_mod,
         *(out_rows if out_rows is not None else (0, 0, 0)),
+        _ptr(cw.w_halo), kT if cw.w_halo is not None else 0,
     )
     L.check(L.load().v3a_conv_bf16(C.byref(args), _stream()), "v3a_conv_bf16")
     return out
