@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp8", "fp8-attn"], default="bf16",
                     help="fp8: config #4's precision mode - DiT self-attention AND the block projection / FFN GEMMs on the e4m3 MFMA "
                          "(per-token / per-channel scales); fp8-attn: the attention only, GEMMs stay bf16")
+    ap.add_argument("--sp-graph", action="store_true",
+                    help="--parallel scene only: replay every rank's sharded DiT forward (RCCL all-gathers included) from a captured hipGraph")
     ap.add_argument("--parallel", choices=["dp", "scene"], default="dp",
                     help="dp: one prompt per GPU, no data-path collective (the reference's split; the headline metric). "
                          "scene: all ranks cooperate on ONE scene (CFG-parallel x sequence-parallel DiT over RCCL; latency mode)")
@@ -175,6 +177,9 @@ def main():
     if coop:
         from vist3a_amd.wan.seqpar import DenoisePlan
         model.pipe.plan = DenoisePlan.from_dist()
+        if a.sp_graph:
+            from vist3a_amd.wan.dit import GraphedWanDiT
+            model.pipe.transformer = GraphedWanDiT(model.transformer, capture_sp=True)
     Tl = (a.num_frames - 1) // 4 + 1
     N = Tl * 32 * 32
 
@@ -213,8 +218,11 @@ def main():
     dt = time.perf_counter() - t0
     probe.active = False
     ops.set_gemm_probe(None)
-    per_rank = None
+    per_rank = rccl_info = None
     if world > 1:
+        # what torch.distributed actually ran on: a SCALE run shows the rank count / backend it saw without a code change
+        rccl_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gpus_visible_to_rank0": torch.cuda.device_count(),
+                     "mode": "scene (CFG x sequence parallel, RCCL all-gathers on the data path)" if coop else "dp (no data-path collective)"}
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         # every rank's wall time and stage times of its last scene (not part of the timed region): shows WHICH stage or rank is slow
@@ -330,13 +338,14 @@ def main():
                                    "VAE decode, 448^2 AnySplat enc_blocks_2 reconstruction with voxel fusion; "
                                    + ("one scene over all GPUs (CFG-parallel x sequence-parallel)" if coop else "1 prompt per GPU (data parallel)"),
                        "denoise_steps": a.denoise_steps, "views": a.num_frames, "dit_tokens": N, "gaussians_last_scene": U,
-                       **({"per_rank_last_scene": per_rank} if per_rank else {}),
+                       **({"per_rank_last_scene": per_rank, "rccl": rccl_info} if per_rank else {}),
                        **({"scene_parallel": {
                            "layout": dict(zip(("cfg_degree", "sp_degree"), DenoisePlan.layout(world))),
                            "sp_mode": ("exact (sp_kv_split = 1): bit-identical to the single-GPU forward" if model.transformer.sp_kv_split == 1 else
                                        "default (sp_kv_split = None): key-split attention + split-K FFN2 on the shards - deterministic, within bf16 "
                                        "rounding (5e-3) of the single-GPU forward, NOT bit-identical"),
-                           "graph": "eager (the sharded forward is not captured: RCCL collectives inside a hipGraph are untested on this pool)",
+                           "graph": ("hipGraph replay of each rank's sharded forward incl. its RCCL all-gathers (--sp-graph)" if a.sp_graph else
+                                     "eager (pass --sp-graph to replay the sharded forward from a captured hipGraph)"),
                            "rccl_all_gather (2 untimed profiled steps, collectives serialised)": comm}} if coop else {}),
                        "stage_ms_last_scene": {"denoise": round(stage.denoise_ms, 1), "vae_decode+resize": round(stage.vae_ms, 1),
                                                "stitch+recon": round(stage.recon_ms, 1)},

@@ -178,8 +178,12 @@ kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, height=256, width=256, nu
 ref = WanT2VPipeline(model, UniPCMultistepScheduler(flow_shift=5.0))(**kw)["frames"].clone()
 out = WanT2VPipeline(model, UniPCMultistepScheduler(flow_shift=5.0), plan=DenoisePlan.from_dist())(**kw)["frames"].clone()
 torch.cuda.synchronize()
+# the same denoise with every rank's sharded forward (its RCCL all-gathers included) replayed from a captured hipGraph
+from vist3a_amd.wan.dit import GraphedWanDiT
+gout = WanT2VPipeline(GraphedWanDiT(model, capture_sp=True), UniPCMultistepScheduler(flow_shift=5.0), plan=DenoisePlan.from_dist())(**kw)["frames"].clone()
+torch.cuda.synchronize()
 res = [None] * dist.get_world_size()
-dist.all_gather_object(res, bool(torch.equal(out, ref)))
+dist.all_gather_object(res, bool(torch.equal(out, ref)) and bool(torch.equal(gout, ref)))
 if dist.get_rank() == 0:
     print(json.dumps(res))
 dist.destroy_process_group()
@@ -206,6 +210,51 @@ def test_rccl_scene_parallel_denoise_matches_single_gpu(hip_lib, tmp_path, world
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("[")][-1]
     assert json.loads(line) == [True] * world
+
+
+_RCCL_CAPTURE_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+from vist3a_amd.wan.seqpar import DistGroup
+grp = DistGroup([0], 0, None)
+inp = torch.arange(1 << 16, device="cuda", dtype=torch.float32)
+out = torch.zeros(1, 1 << 16, device="cuda")
+grp.all_gather(out, inp).wait()          # eager warm-up: communicator set-up must not happen under capture
+torch.cuda.synchronize()
+out.zero_()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    grp.all_gather(out, inp).wait()
+    y = out * 2
+ok = []
+for k in range(3):
+    inp.add_(1.0)
+    g.replay()
+    torch.cuda.synchronize()
+    ok.append(bool(torch.equal(out[0], inp)) and bool(torch.equal(y[0], inp * 2)))
+print(json.dumps(ok))
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_all_gather_is_capturable_in_a_hipgraph(hip_lib, tmp_path):
+    """DistGroup.all_gather (async RCCL all_gather_into_tensor + wait) inside a captured hipGraph on a one-rank communicator: the replay
+    must re-run the collective on the current contents of its input.  What GraphedWanDiT(capture_sp=True) relies on; the multi-rank
+    form runs inside test_rccl_scene_parallel_denoise_matches_single_gpu whenever more than one GPU is visible."""
+    import os, subprocess, sys, json
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    script = tmp_path / "cap.py"
+    script.write_text(_RCCL_CAPTURE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), str(root)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("[")][-1]
+    assert json.loads(line) == [True, True, True]
 
 
 def _tiny_dit():

@@ -327,19 +327,28 @@ def test_full_depth_production_size_forward_matches_oracle(hip_lib, parity):
     outs = {L: model(lat.cuda(), t.cuda(), text.cuda(), num_layers=L)[0].float().cpu() for L in depths}
     out = outs[30]
     torch.cuda.synchronize()
-    with torch.no_grad():
+    import oracle_cache as OC
+
+    def compute():
         ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
         # the same forward with the two CONTRACT differences of the HIP path emulated as well: bf16 P per 64-key flash tile (every
         # flash kernel has that term, the reference's SDPA included) and the merged zero-padding key of the cross-attention
         taps = {L: None for L in depths}
         ref_c = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, depth_outputs=taps)
-    r, rc, floor = _rel(out, ref), _rel(out, ref_c), _rel(ref_c, ref)
-    curve = {L: _rel(outs[L], taps[L]) for L in depths}
-    mx = (out - ref).abs().max().item()
+        d = dict(ref=ref, ref_c=ref_c, ref_rms=ref.pow(2).mean().sqrt().item())
+        d.update({f"depth{L}": taps[L] for L in depths})
+        return d
+
+    # (the two 30-block oracle forwards take ~2 minutes of host time: committed digest, tests/oracle_cache.py)
+    od, live = OC.oracle("dit_full_depth_30_blocks_N4096", OC.checksum(lat, text, sd["blocks.0.attn1.to_q.weight"], sd["blocks.29.ffn.net.2.weight"]), compute)
+    r, rc, floor = OC.rel(out, od["ref"]), OC.rel(out, od["ref_c"]), OC.rel_dd(od["ref_c"], od["ref"])
+    curve = {L: OC.rel(outs[L], od[f"depth{L}"]) for L in depths}
+    mx = (OC.digest(out) - od["ref"]).abs().max().item()
     parity("dit_full_depth_30_blocks_N4096", rel_vs_emu_oracle=r, rel_vs_contract_oracle=rc, oracle_contract_vs_exact_softmax=floor,
-           rel_vs_contract_oracle_by_depth={str(k): v for k, v in curve.items()}, max_abs=mx, ref_rms=ref.pow(2).mean().sqrt().item())
+           rel_vs_contract_oracle_by_depth={str(k): v for k, v in curve.items()}, max_abs=mx, ref_rms=float(od["ref_rms"].item()),
+           oracle="live" if live else "digest fixture")
     print(f"full-depth 30-block N=4096 forward: rel {r:.3e} (exact-softmax oracle), {rc:.3e} (kernel-contract oracle); the two oracles differ "
-          f"by {floor:.3e}; by depth {', '.join(f'{k}: {v:.2e}' for k, v in curve.items())}; max abs {mx:.3e}")
+          f"by {floor:.3e}; by depth {', '.join(f'{k}: {v:.2e}' for k, v in curve.items())}; max abs {mx:.3e} ({'live' if live else 'fixture'})")
     assert torch.isfinite(out).all()
     # Round 3 finding: HIP, the exact-softmax oracle and the contract oracle are MUTUALLY ~9e-3 apart after 30 blocks - two restatements
     # of the same arithmetic that differ only in where P is rounded land as far from each other as the kernels land from either.  The
@@ -515,6 +524,56 @@ def test_seq_parallel_production_width_reads_gathered_slabs_in_place(hip_lib, P)
         assert torch.equal(o, full)
     for o in outs_split:
         assert torch.equal(o, outs_split[0]) and _rel(o, full) < 5e-3, _rel(o, full)   # bf16 rounding of the merged softmax
+
+
+def test_sharded_forward_replays_from_a_hipgraph_bit_identically(hip_lib):
+    """GraphedWanDiT(capture_sp=True): a rank's sequence-parallel forward at production width (1024 of 4096 tokens: P = 4, two blocks,
+    both the exact and the default key-split / split-K modes) captured in a hipGraph WITH its per-block all-gathers and replayed on new
+    inputs equals the eager sharded forward bit for bit.  The group is a device-side stand-in (every segment = the local slab, as in
+    tools/sp_rank_time.py) because one GPU cannot host P capturing ranks; that RCCL's all-gather itself captures and replays is
+    tests/test_boundary_gpu.py::test_rccl_all_gather_is_capturable_in_a_hipgraph, and the real multi-rank graph run is the second leg of
+    test_rccl_scene_parallel_denoise_matches_single_gpu."""
+    import dataclasses
+    from vist3a_amd.wan.dit import WAN_1_3B, GraphedWanDiT, WanDiT
+    from vist3a_amd.wan.weights import random_dit_state_dict
+
+    class _Done:
+        def wait(self):
+            return None
+
+    class SelfGather:
+        graph_safe = True
+
+        def __init__(self, world):
+            self.world, self.rank, self.calls = world, 1, 0
+
+        def all_gather(self, out, inp):
+            self.calls += 1
+            out.view(self.world, -1).copy_(inp.reshape(1, -1).expand(self.world, -1))
+            return _Done()
+
+    cfg = dataclasses.replace(WAN_1_3B, num_layers=2)
+    m = WanDiT(cfg, random_dit_state_dict(cfg, seed=0, device="cuda"))
+    gm = GraphedWanDiT(m, capture_sp=True)
+    g = torch.Generator().manual_seed(5)
+    text = (torch.randn(1, 512, 4096, generator=g) * 0.1).cuda()
+    text[:, 70:] = 0
+    for mode in (1, None):
+        m.sp_kv_split = mode
+        sp = SelfGather(4)
+        for k, tval in enumerate((700, 300, 40)):
+            lat = torch.randn(1, 16, 4, 64, 64, generator=g).bfloat16().cuda()
+            t = torch.tensor([tval]).cuda()
+            want = m(lat, t, text, sp=sp)[0].clone()
+            calls = sp.calls
+            got = gm(lat, t, text, sp=sp)[0].clone()
+            if k > 0:
+                assert sp.calls == calls, "the replay went through the Python forward"
+            assert torch.equal(got, want)
+    assert len(gm._graphs) == 2
+    # a group that synchronises through the host is never captured
+    from vist3a_amd.wan.seqpar import ThreadWorld
+    assert ThreadWorld(2).group(0).graph_safe is False
 
 
 def test_config4_seq_parallel_14b_width_P8_e4m3_slabs_in_place(hip_lib):

@@ -7,14 +7,16 @@
     reconstruction layout (21 x 1032 rows, 21 609 keys in the global attention) at full resolution vs the oracle at reduced width,
     and a production-width S = 21 run checked through size-independent properties.
 
-The oracle runs on the GPU box's host cores (fp32, ~1 + ~2.5 minutes for the first two); nothing here reads /root/reference.  Every
-measured error goes to parity.json through the `parity` fixture; asserts sit at <= 2x the value measured on MI355X."""
+The VAE / DiT oracles run live on the GPU box's host cores (~1 minute); the two reconstruction oracles (11 + 4.5 minutes live) come from
+committed digests of the same oracle code's outputs (tests/oracle_cache.py; V3A_LIVE_ORACLE=1 runs them live).  Nothing here reads
+/root/reference.  Every measured error goes to parity.json through the `parity` fixture; asserts sit at <= 2x the value measured on MI355X."""
 import pytest
 import torch
 
 from oracle import recon as R
 from oracle import wan_dit as O
 from oracle import wan_vae as OV
+import oracle_cache as OC
 
 pytestmark = pytest.mark.gpu
 
@@ -56,11 +58,17 @@ def test_full_size_vae_decode_matches_oracle(hip_lib, parity):
           f"(oracle {t_oracle:.0f} s); quarter size: vs contract {small['rel_vs_contract']:.3e}, vs fp32 {small['rel_vs_fp32']:.3e}, "
           f"contract vs fp32 {small['contract_vs_fp32']:.3e}")
     assert torch.isfinite(out).all() and sat < 0.5
+    # MI355X, round 4: 1.48e-2 vs the contract oracle (1.34e-2 vs fp32 in round 3), quarter size 1.51e-2 / 1.35e-2 - while the oracle's own
+    # two forms are 1.37e-2 apart: 35 bf16 conv layers put ANY two restatements of this decoder (different fp32 summation order is enough)
+    # ~1.4e-2 from each other, i.e. the rounding-point emulation cannot bring two implementations closer than the network's conditioning
+    # (2^-9 / sqrt(3) per rounding x sqrt(~100 roundings along a path)).  The kernel-level errors are 6e-5 (tests/test_kernels_gpu.py).
+    # Gates: <= 2x measured, and HIP no further from the contract oracle than 2x the oracle's contract-vs-fp32 spread.
     assert r < VAE_FULL_GATE and small["rel_vs_contract"] < VAE_FULL_GATE, (r, small)
+    assert small["rel_vs_contract"] < 2.0 * small["contract_vs_fp32"] and r < 2.0 * small["contract_vs_fp32"], (r, small)
     assert small["rel_vs_fp32"] < 2.6e-2        # informational figure, round-3 gate (1.3e-2 measured at full size)
 
 
-VAE_FULL_GATE = 1.0e-2    # <= 2x the measured HIP-vs-contract figure (set from the first MI355X run of this test, see profiles/r4/parity.json)
+VAE_FULL_GATE = 2.9e-2    # <= 2x the measured HIP-vs-contract figure (1.48e-2 on MI355X, profiles/r4/parity.json)
 
 
 @pytest.fixture(scope="module")
@@ -104,33 +112,52 @@ def test_full_size_reconstruction_matches_oracle(recon_full, parity):
     eng = model.stitched_3d_model.engine()
     _, geo = eng.token_workspace(S, H, H)
     taps = [t.view(S, geo["Pp"], -1)[:, :geo["P"]].float().cpu() for t in geo["taps"]]
-    with torch.no_grad():
+
+    def compute():
         t0 = time.time()
         feat_c = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
         ctaps = R.backbone(sd, feat_c, 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth, emulate_bf16=True)
         t1 = time.time()
         ora = R.recon_forward(sd, ocfg, feat_c, img, toks=ctaps)
         t2 = time.time()
-    tap_c = [_rel(t, o[0]) for t, o in zip(taps, ctaps)]
-    e = dict(pose=_rel(eo.pred_pose_enc_list[-1], ora["pred_pose_enc_list"][-1]), depth=_rel(eo.depth_dict["depth"], ora["depth"]),
-             depth_conf=_rel(dconf, ora["depth_conf"]), raw_gs=_rel(anchor, ora["raw_gs"][:, :, :83]), gs_conf=_rel(conf, ora["raw_gs"][:, :, 83]),
-             c2w=_rel(eo.pred_context_pose["extrinsic"], ora["pred_context_pose"]["extrinsic"]),
-             intrinsic=_rel(eo.pred_context_pose["intrinsic"], ora["pred_context_pose"]["intrinsic"]))
-    U, Uo = eo.gaussians.means.shape[1], ora["gaussians"]["means"].shape[1]
-    parity("recon_full_size_C1024_H16_S13", taps_vs_contract=tap_c, voxels=U, voxels_oracle=Uo,
-           oracle_seconds=dict(backbone_contract=t1 - t0, heads=t2 - t1), **e)
-    print("full-size recon taps vs contract", [f"{t:.2e}" for t in tap_c], {k: f"{v:.2e}" for k, v in e.items()}, "voxels", U, "oracle", Uo,
-          f"oracle s: {t1 - t0:.0f} + {t2 - t1:.0f}")
+        # plain fp32 backbone as well (informational: how far the reference's own rounding points move the taps)
+        ftaps = R.backbone(sd, R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1)), 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth)
+        t3 = time.time()
+        d = {f"tap{i}": c[0] for i, c in enumerate(ctaps)}
+        d.update({f"tap{i}_fp32": c[0] for i, c in enumerate(ftaps)})
+        d.update(pose=ora["pred_pose_enc_list"][-1], depth=ora["depth"], depth_conf=ora["depth_conf"], raw_gs=ora["raw_gs"][:, :, :83],
+                 gs_conf=ora["raw_gs"][:, :, 83], c2w=ora["pred_context_pose"]["extrinsic"], intrinsic=ora["pred_context_pose"]["intrinsic"],
+                 voxels=ora["gaussians"]["means"].shape[1], seconds_backbone_contract=t1 - t0, seconds_heads=t2 - t1, seconds_backbone_fp32=t3 - t2)
+        return d
+
+    ora, live = OC.oracle("recon_full_C1024_S13", OC.checksum(lat, img, w, b, sd["encoder.aggregator.frame_blocks.0.attn.qkv.weight"],
+                                                               sd["encoder.gaussian_param_head.scratch.output_conv2.2.weight"]), compute)
+    tap_c = [OC.rel(t, ora[f"tap{i}"]) for i, t in enumerate(taps)]
+    tap_32 = [OC.rel(t, ora[f"tap{i}_fp32"]) for i, t in enumerate(taps)]
+    floor = [OC.rel_dd(ora[f"tap{i}"], ora[f"tap{i}_fp32"]) for i in range(len(taps))]
+    e = dict(pose=OC.rel(eo.pred_pose_enc_list[-1], ora["pose"]), depth=OC.rel(eo.depth_dict["depth"], ora["depth"]),
+             depth_conf=OC.rel(dconf, ora["depth_conf"]), raw_gs=OC.rel(anchor, ora["raw_gs"]), gs_conf=OC.rel(conf, ora["gs_conf"]),
+             c2w=OC.rel(eo.pred_context_pose["extrinsic"], ora["c2w"]), intrinsic=OC.rel(eo.pred_context_pose["intrinsic"], ora["intrinsic"]))
+    U, Uo = eo.gaussians.means.shape[1], int(ora["voxels"].item())
+    secs = {k[8:]: round(float(v.item()), 1) for k, v in ora.items() if k.startswith("seconds_")}
+    parity("recon_full_size_C1024_H16_S13", taps_vs_contract=tap_c, taps_vs_fp32=tap_32, taps_contract_vs_fp32=floor, voxels=U, voxels_oracle=Uo,
+           oracle="live" if live else "digest fixture", oracle_seconds=secs, **e)
+    print("full-size recon taps vs contract", [f"{t:.2e}" for t in tap_c], "vs fp32", [f"{t:.2e}" for t in tap_32], "contract vs fp32",
+          [f"{t:.2e}" for t in floor], {k: f"{v:.2e}" for k, v in e.items()}, "voxels", U, "oracle", Uo, "live" if live else "fixture", secs)
     assert all(torch.isfinite(t).all() for t in taps)
-    # gates at <= 2x the HIP-vs-contract figures measured on MI355X (profiles/r4/parity.json); round 3 measured against the fp32 oracle:
-    # taps 9.2e-3 / 8.1e-3 / 7.7e-3 / 7.1e-3, pose 2.8e-3, depth 3.9e-3, depth_conf 1.7e-3, raw_gs 9.3e-3, gs_conf 1.4e-2, c2w 4.2e-3
+    # MI355X (round 4, contract oracle): taps 9.7e-3 / 8.6e-3 / 8.1e-3 / 7.5e-3, pose 2.8e-3, depth 4.0e-3, depth_conf 1.8e-3, raw_gs 9.4e-3,
+    # gs_conf 1.4e-2, c2w 5.2e-3 - the same as against the plain fp32 oracle in round 3 (9.2e-3 .. 7.1e-3): like the DiT (test_dit_gpu.py,
+    # full-depth test), HIP, the contract oracle and the fp32 oracle are MUTUALLY ~1e-2 apart after 70 bf16 blocks - rounding-point
+    # conditioning, not a kernel error.  Gates: <= 2x measured, and HIP no further from the contract oracle than 2x the oracle's own
+    # contract-vs-fp32 spread.
     assert max(tap_c) < RECON_GATES["taps"], tap_c
+    assert all(c < 2.0 * f for c, f in zip(tap_c, floor)), (tap_c, floor)
     for k in ("pose", "depth", "depth_conf", "raw_gs", "gs_conf", "c2w", "intrinsic"):
         assert e[k] < RECON_GATES[k], (k, e[k])
     assert abs(U - Uo) <= 0.03 * Uo
 
 
-RECON_GATES = dict(taps=1.8e-2, pose=5.6e-3, depth=7.8e-3, depth_conf=3.5e-3, raw_gs=1.9e-2, gs_conf=2.8e-2, c2w=8.4e-3, intrinsic=1e-4)
+RECON_GATES = dict(taps=1.9e-2, pose=5.6e-3, depth=7.9e-3, depth_conf=3.5e-3, raw_gs=1.9e-2, gs_conf=2.8e-2, c2w=1.0e-2, intrinsic=1e-4)
 
 
 def test_config3_21_view_dit_forward_matches_oracle(hip_lib, parity):
@@ -177,27 +204,41 @@ def test_config3_21_view_reconstruction_layout_matches_oracle(hip_lib, parity):
     img = torch.rand(1, 3, S, H, H, generator=g) * 2 - 1
     eo, anchor, conf, dconf = model.forward_with_latent(lat.cuda(), img.cuda(), train=True)
     torch.cuda.synchronize()
-    with torch.no_grad():
+    eng = model.stitched_3d_model.engine()
+    _, geo = eng.token_workspace(S, H, H)
+    taps = [t_.view(S, geo["Pp"], -1)[:, :geo["P"]].float().cpu() for t_ in geo["taps"]]
+
+    def compute():
         feat = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
         ora = R.recon_forward(sd, ocfg, feat, img, emulate_bf16=True)                       # the reference's GPU rounding points, fp32 heads
         dev = R.recon_forward(sd, ocfg, feat, img, dpt_bf16=True, toks=ora["taps"])         # + the HIP path's documented bf16 DPT heads
         o32 = R.recon_forward(sd, ocfg, R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1)), img)   # plain fp32 (informational)
-    errs = lambda o: dict(pose=_rel(eo.pred_pose_enc_list[-1], o["pred_pose_enc_list"][-1]), depth=_rel(eo.depth_dict["depth"], o["depth"]),
-                          depth_conf=_rel(dconf, o["depth_conf"]), raw_gs=_rel(anchor, o["raw_gs"][:, :, :83]))
-    e, ed, e32 = errs(ora), errs(dev), errs(o32)
-    eng = model.stitched_3d_model.engine()
-    _, geo = eng.token_workspace(S, H, H)
-    taps = [t_.view(S, geo["Pp"], -1)[:, :geo["P"]].float().cpu() for t_ in geo["taps"]]
-    tap_c, tap_32 = [_rel(a, c[0]) for a, c in zip(taps, ora["taps"])], [_rel(a, c[0]) for a, c in zip(taps, o32["taps"])]
-    floor = [_rel(c[0], o[0]) for c, o in zip(ora["taps"], o32["taps"])]
-    price = dict(depth=_rel(dev["depth"], ora["depth"]), raw_gs=_rel(dev["raw_gs"], ora["raw_gs"]))
-    U, Uo = eo.gaussians.means.shape[1], ora["gaussians"]["means"].shape[1]
+        d = {}
+        for tag, o in (("c", ora), ("d", dev), ("f", o32)):
+            d.update({f"{tag}_pose": o["pred_pose_enc_list"][-1], f"{tag}_depth": o["depth"], f"{tag}_depth_conf": o["depth_conf"],
+                      f"{tag}_raw_gs": o["raw_gs"][:, :, :83], f"{tag}_raw_all": o["raw_gs"]})
+        d.update({f"c_tap{i}": c[0] for i, c in enumerate(ora["taps"])})
+        d.update({f"f_tap{i}": c[0] for i, c in enumerate(o32["taps"])})
+        d["voxels"] = ora["gaussians"]["means"].shape[1]
+        return d
+
+    od, live = OC.oracle("recon_config3_S21_width128", OC.checksum(lat, img, w, b, sd["encoder.aggregator.frame_blocks.0.attn.qkv.weight"]), compute)
+    errs = lambda tag: dict(pose=OC.rel(eo.pred_pose_enc_list[-1], od[tag + "_pose"]), depth=OC.rel(eo.depth_dict["depth"], od[tag + "_depth"]),
+                            depth_conf=OC.rel(dconf, od[tag + "_depth_conf"]), raw_gs=OC.rel(anchor, od[tag + "_raw_gs"]))
+    e, ed, e32 = errs("c"), errs("d"), errs("f")
+    nt = len(taps)
+    tap_c, tap_32 = [OC.rel(a, od[f"c_tap{i}"]) for i, a in enumerate(taps)], [OC.rel(a, od[f"f_tap{i}"]) for i, a in enumerate(taps)]
+    floor = [OC.rel_dd(od[f"c_tap{i}"], od[f"f_tap{i}"]) for i in range(nt)]
+    price = dict(depth=OC.rel_dd(od["d_depth"], od["c_depth"]), raw_gs=OC.rel_dd(od["d_raw_all"], od["c_raw_all"]))
+    U, Uo = eo.gaussians.means.shape[1], int(od["voxels"].item())
     parity("recon_config3_S21_448_width128", voxels=U, voxels_oracle=Uo, vs_contract=e, vs_contract_with_bf16_dpt_heads=ed, vs_fp32=e32,
-           bf16_dpt_heads_move_the_oracle_by=price, taps_vs_contract=tap_c, taps_vs_fp32=tap_32, taps_contract_vs_fp32=floor)
+           bf16_dpt_heads_move_the_oracle_by=price, taps_vs_contract=tap_c, taps_vs_fp32=tap_32, taps_contract_vs_fp32=floor,
+           oracle="live" if live else "digest fixture")
     print("config #3 recon layout (S=21 @448, width 128): vs contract", {k: f"{v:.2e}" for k, v in e.items()}, "vs contract + bf16 DPT heads",
           {k: f"{v:.2e}" for k, v in ed.items()}, "price of the bf16 heads", {k: f"{v:.2e}" for k, v in price.items()}, "vs fp32", {k: f"{v:.2e}" for k, v in e32.items()},
           "taps vs contract", [f"{x:.2e}" for x in tap_c], "vs fp32", [f"{x:.2e}" for x in tap_32], "contract vs fp32", [f"{x:.2e}" for x in floor],
-          "voxels", U, "oracle", Uo)
+          "voxels", U, "oracle", Uo, "live" if live else "fixture")
+    assert all(c < 2.0 * f for c, f in zip(tap_c, floor)), (tap_c, floor)   # measured 1.2e-2 .. 1.0e-2 against a 1.1e-2 oracle spread
     assert e["pose"] < 9e-3 and e["depth"] < 7.4e-3 and e["depth_conf"] < 3.8e-3 and e["raw_gs"] < 1.65e-2   # round 3 vs fp32: 4.6e-3 / 3.7e-3 / 1.9e-3 / 8.2e-3
     assert abs(U - Uo) <= 0.03 * Uo      # measured -1.3 %
 

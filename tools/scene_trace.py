@@ -1,0 +1,39 @@
+"""Kernel histogram of exactly ONE scene's worth of work (50-step denoise + VAE decode + reconstruction), no bench extras:
+   rocprofv3 --kernel-trace --output-format csv -d DIR -- python tools/scene_trace.py ; python tools/scene_trace.py --report DIR
+Two scenes are run; the report keeps every kernel after the END of the first scene's 50th unipc_cfg_step launch, i.e. the first
+scene's VAE + reconstruction and the second scene's denoise - one of each stage in steady state - and lists the kernels that are NOT
+this library's (torch elementwise / copy / fill launches: host glue) separately."""
+import csv, collections, glob, json, sys
+from pathlib import Path
+
+if len(sys.argv) > 2 and sys.argv[1] == "--report":
+    f = glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True)[0]
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
+    steps = [i for i, r in enumerate(rows) if "unipc_cfg_step_kernel" in r[2]]
+    n = len(steps) // 2
+    first, last = steps[n - 1] + 1, steps[-1] + 1
+    sel = rows[first:last]
+    busy = sum(e - s for s, e, _ in sel) / 1e3
+    acc = collections.defaultdict(list)
+    for s, e, nme in sel:
+        nme = nme.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        acc[nme[:110]].append((e - s) / 1e3)
+    ours = lambda k: not (k.startswith("void at::") or k.startswith("__amd_rocclr") or k.startswith("at::") or "rocprim" in k)
+    glue = {k: v for k, v in acc.items() if not ours(k) and "rocprim" not in k}
+    print(json.dumps(dict(kernels=len(sel), busy_ms=round(busy / 1e3, 2), span_ms=round((sel[-1][1] - sel[0][0]) / 1e6, 2),
+                          glue_launches=sum(len(v) for v in glue.values()), glue_ms=round(sum(sum(v) for v in glue.values()) / 1e3, 3),
+                          glue_share_pct=round(100 * sum(sum(v) for v in glue.values()) / busy, 3))))
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[: int(sys.argv[3]) if len(sys.argv) > 3 else 60]:
+        print(f"{'  ' if ours(k) else 'G '}{k:112s} n {len(v):5d} avg_us {sum(v) / len(v):9.1f} max_us {max(v):9.1f} sum_ms {sum(v) / 1e3:9.3f} {100 * sum(v) / busy:6.3f}%")
+    sys.exit(0)
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch
+from vist3a_amd.t23d import Text23DGS, synthetic_text_embeddings
+from vist3a_amd.wan.dit import WAN_1_3B
+model = Text23DGS.synthetic(WAN_1_3B, seed=0, device="cuda")
+pe, ne = synthetic_text_embeddings("cuda")
+for i in range(2):
+    lat0 = torch.randn(1, 16, 4, 64, 64, generator=torch.Generator().manual_seed(12413 + i))
+    model.generate(pe, ne, latents=lat0, num_frames=13, num_inference_steps=50, guidance_scale=7.5)
+torch.cuda.synchronize()

@@ -224,15 +224,18 @@ class ReconEngine:
             ops.attention(q, k, g["vt"], g["ao"], B=S, H=H, Nq=P, Nk=P, D=C // H, q_batch_stride=Pp * 2 * C,
                           k_batch_stride=Pp * 2 * C, vt_batch_stride=Pp, o_batch_stride=Pp * C)
 
-    def _block(self, g, blk, x, S, glob, rope, eps):
-        """x: residual stream (bf16 for DINO, f32 for the aggregator), updated in place."""
+    def _block(self, g, blk, x, S, glob, rope, eps, xo=None):
+        """x: residual stream (bf16 for DINO, f32 for the aggregator).  The block's output goes to `xo` (default: x, in place); with
+        xo != x the attention branch already lands in xo (residual read from x), so x is left untouched - how the tapped aggregator
+        blocks write their output straight into the [M, 2C] tap buffers (row stride 2C) instead of being copied there afterwards."""
         f = x.dtype == f32
+        xo = x if xo is None else xo
         ops.layernorm(x, out=g["n"], weight=blk.n1w, bias=blk.n1b, eps=eps)
         self._attn(g, blk, S, glob, rope)
-        ops.gemm(g["ao"], blk.wo, blk.bo, out=x, residual=x, scale=blk.ls1, round_after_scale=True, out_f32=f)
-        ops.layernorm(x, out=g["n"], weight=blk.n2w, bias=blk.n2b, eps=eps)
+        ops.gemm(g["ao"], blk.wo, blk.bo, out=xo, residual=x, scale=blk.ls1, round_after_scale=True, out_f32=f)
+        ops.layernorm(xo, out=g["n"], weight=blk.n2w, bias=blk.n2b, eps=eps)
         ops.gemm(g["n"], blk.w1, blk.b1, out=g["h"], act=L.ACT_GELU_ERF)
-        ops.gemm(g["h"], blk.w2, blk.b2, out=x, residual=x, scale=blk.ls2, round_after_scale=True, out_f32=f)
+        ops.gemm(g["h"], blk.w2, blk.b2, out=xo, residual=xo, scale=blk.ls2, round_after_scale=True, out_f32=f)
 
     def backbone(self, g, S):
         """x (bf16 tokens incl. DINO specials) -> tapped [M, 2C] f32 intermediates."""
@@ -244,16 +247,19 @@ class ReconEngine:
             self._block(g, blk, x, S, False, False, 1e-6)
         ops.layernorm(x, out=xf, weight=self.dino_nw, bias=self.dino_nb, eps=1e-6)
         xf.view(S, Pp, C)[:, :nsp] = g["special_agg"]
-        ti = 0
+        # The residual stream walks THROUGH the tap buffers (anysplat_stitched.py:249-325 concatenates the frame and global intermediates
+        # of the tapped layers): a tapped frame block writes its output into the left half of the tap, the global block reads it there
+        # and writes the right half, the next frame block reads that and returns to xf.  No concatenation copies (8 x 55 MB per scene).
+        cur, ti = xf, 0
         for li in range(cfg.depth):
-            self._block(g, self.frame[li], xf, S, False, True, 1e-5)
             tap = li in cfg.taps
-            if tap:
-                g["taps"][ti][:, :C] = xf
-            self._block(g, self.glob[li], xf, S, True, True, 1e-5)
-            if tap:
-                g["taps"][ti][:, C:] = xf
-                ti += 1
+            dst = g["taps"][ti][:, :C] if tap else xf
+            self._block(g, self.frame[li], cur, S, False, True, 1e-5, xo=dst)
+            cur = dst
+            dst = g["taps"][ti][:, C:] if tap else xf
+            self._block(g, self.glob[li], cur, S, True, True, 1e-5, xo=dst)
+            cur = dst
+            ti += int(tap)
         return g["taps"]
 
     # ------------------------------------------------------------------ camera head (fp32)

@@ -512,35 +512,41 @@ class GraphedWanDiT:
     them latency-bound (time embedding, norms at M = B rows, patchify); replaying a captured graph removes the host launch
     path from the 50-step loop.  Inputs are copied into static buffers, the prompt context lives in WanDiT's persistent
     buffers, so ONE capture per latent shape serves every step of every prompt.  While a GemmProbe is active (bench.py's
-    roofline leg brackets individual launches with events) the call runs eagerly."""
+    roofline leg brackets individual launches with events) the call runs eagerly.
+    `capture_sp=True` also captures the SEQUENCE-PARALLEL forward (wan/seqpar.py) - its per-block all-gathers included - for groups that
+    declare `graph_safe` (DistGroup: RCCL collectives enqueue on the capturing stream; the thread-backed ThreadGroup of the 1-GPU tests
+    synchronises through the host and is never captured).  A rank's sharded forward is 17 launches of ~10 us per block
+    (tools/sp_rank_time.py), exactly where the host launch path shows.  One graph per (shape, group, rank)."""
 
-    def __init__(self, dit: WanDiT):
+    def __init__(self, dit: WanDiT, capture_sp: bool = False):
         self.dit, self.cfg, self.device, self.dtype = dit, dit.cfg, dit.device, dit.dtype
+        self.capture_sp = capture_sp
         self._graphs: Dict[tuple, tuple] = {}
 
     @torch.no_grad()
     def __call__(self, hidden_states, timestep, encoder_hidden_states, return_dict: bool = False, num_layers=None, sp=None):
         pr = ops._probe
-        if sp is not None or num_layers is not None or (pr is not None and pr.active):
+        sp_ok = sp is None or (self.capture_sp and getattr(sp, "graph_safe", False) and not getattr(sp, "profile", False))
+        if not sp_ok or num_layers is not None or (pr is not None and pr.active):
             return self.dit.forward(hidden_states, timestep, encoder_hidden_states, return_dict, num_layers, sp)
         text = encoder_hidden_states
         lk = self.dit._context(text)[5]  # eager: refreshes the persistent K / V^T buffers when the prompt changed
         d = self.dit   # the precision modes are baked into a capture: a flipped mode must not replay the old-precision graph
         key = (tuple(hidden_states.shape), tuple(text.shape), lk, threading.get_ident(), d.attn_dtype, d.gemm_dtype, tuple(d.fp8_scales),
-               d.merge_padding_keys)
+               d.merge_padding_keys, None if sp is None else (id(sp), sp.world, sp.rank, d.sp_kv_split))
         ent = self._graphs.get(key)
         if ent is None:
             sx = torch.empty(hidden_states.shape, device=self.device, dtype=bf16)
             st = torch.empty(timestep.shape, device=self.device, dtype=timestep.dtype)
             sx.copy_(hidden_states)
             st.copy_(timestep)
-            self.dit.forward(sx, st, text)  # eager warm-up: workspaces, kernel attributes, rope tables
+            self.dit.forward(sx, st, text, sp=sp)  # eager warm-up: workspaces, kernel attributes, rope tables (and the communicator)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                out = self.dit.forward(sx, st, text)[0]
-            ent = self._graphs[key] = (g, sx, st, out)
-        g, sx, st, out = ent
+                out = self.dit.forward(sx, st, text, sp=sp)[0]
+            ent = self._graphs[key] = (g, sx, st, out, sp)   # (the group stays referenced: its id is part of the key)
+        g, sx, st, out = ent[:4]
         sx.copy_(hidden_states)
         st.copy_(timestep)
         g.replay()

@@ -34,6 +34,9 @@ class _Done:
 class DistGroup:
     """torch.distributed backend (RCCL over xGMI on GPUs, gloo on CPU)."""
 
+    # the collectives are enqueued on the calling stream (no host rendezvous per call): GraphedWanDiT(capture_sp=True) may capture them
+    graph_safe = True
+
     def __init__(self, ranks: List[int], my_global_rank: int, pg):
         self.ranks, self.world, self.rank, self.pg = list(ranks), len(ranks), list(ranks).index(my_global_rank), pg
         # measurement mode (bench.py --parallel scene, AFTER its timed region): every all-gather runs synchronously between two events
@@ -99,6 +102,8 @@ class ThreadWorld:
 
 
 class ThreadGroup:
+    graph_safe = False   # host barriers between threads: cannot be captured
+
     def __init__(self, w: ThreadWorld, rank: int):
         self.w, self.rank, self.world = w, rank, w.world
 
