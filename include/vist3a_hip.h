@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 17) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 18) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -73,6 +73,12 @@ typedef struct {
                          * into bf16 partials, summed in slice order by a second launch that applies the epilogue - for problems with
                          * few output tiles and a long K (a sequence-parallel shard's FFN2).  Deterministic; not bit-identical to 0 / 1. */
   void* workspace;      /* split_k > 1: v3a_gemm_split_workspace_bytes(M, N, split_k) bytes */
+  int batch;            /* > 1 (v3a_gemm_bf16_nt, not with split_k): `batch` equally shaped problems side by side in ONE launch; problem z
+                         * reads A + z * a_batch_stride, B + z * b_batch_stride, writes C + z * c_batch_stride, adds residual +
+                         * z * res_batch_stride (strides in ELEMENTS of the respective tensor; 0 = shared).  bias / scale / residual2 are
+                         * shared.  Used for per-head and per-prompt operands (the cached-context cross-attention of the DiT: one B
+                         * operand per CFG batch item) where separate launches would each fill a fraction of the chip. */
+  long a_batch_stride, b_batch_stride, c_batch_stride, res_batch_stride;
 } v3a_gemm_args;
 int v3a_gemm_bf16_nt(const v3a_gemm_args* args, void* stream);
 size_t v3a_gemm_split_workspace_bytes(int M, int N, int split_k);
@@ -176,6 +182,26 @@ typedef struct {
 } v3a_attn_args;
 int v3a_attention_fwd_bf16(const v3a_attn_args* args, void* stream);
 size_t v3a_attention_split_workspace_bytes(int B, int H, int Nq, int D, int kv_split);
+
+/* ------------------------------------------------------------------------------------------------
+ * Cross-attention PROBABILITIES over a short per-prompt key set (csrc/xattn_probs.hip): the first half of the cached-context form
+ *     attn2(x) = softmax(q K^T) V Wo^T + bo = sum_h P_h (V_h Wo_h^T) + bo
+ * of diffusers==0.33.1 WanTransformerBlock.attn2 (call site /root/reference/inference_t23d.py:94-103).  K, V depend on the prompt only:
+ * the host caches (V_h Wo_h^T) per prompt and v3a_gemm_bf16_nt (batch = CFG items, K = H * Lkp) finishes the layer.
+ *   p[b][m][h * Lkp + j] = bf16( softmax_j( scale * q[b][m][h*D:(h+1)*D] . k[b][j][h*D:(h+1)*D] + key_bias[b][j] ) ),  j < Nk;  0 for
+ *   Nk <= j < Lkp.  D = 128, Nk <= 128, Lkp % 16 == 0, Nk <= Lkp <= 128, ldp >= H * Lkp.  key_bias (optional, f32 [B][key_bias_stride])
+ *   is added for keys >= key_bias_first (the merged zero-padding key carries log(count), v3a_attn_args.key_bias).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q; const void* k; void* p;      /* bf16 */
+  const float* key_bias;
+  long q_batch_stride, k_batch_stride, p_batch_stride;   /* elements */
+  int ldq, ldk, ldp;
+  int B, H, Nq, Nk, D, Lkp;
+  int key_bias_stride, key_bias_first;
+  float scale;
+} v3a_xattn_probs_args;
+int v3a_xattn_probs_bf16(const v3a_xattn_probs_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) flash attention forward on the block-scaled MFMA (K = 64, twice the bf16 rate): the self-attention launch of

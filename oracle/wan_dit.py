@@ -206,7 +206,29 @@ def condition_embed(sd, cfg, timestep, text, emu):
     return temb, tproj, ctx
 
 
-def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gemm=False, flash=False, ctx_keys=None, fp16_norm=False):
+def cross_attention_ctx_vo(q, k, v, heads, wo, bo, key_bias=None):
+    """Rounding points of the product's cached-context cross-attention (vist3a_amd/wan/dit.py `ctx_vo`, csrc/xattn_probs.hip):
+        attn2 = sum_h bf16(softmax_h(q K^T)) . bf16(bf16(V_h) Wo_h^T) + bo        (fp32 accumulation, one bf16 rounding of the result)
+    instead of  bf16(softmax(q K^T) V) Wo^T + bo.  Equal in real arithmetic; NOT the reference's order of operations (diffusers runs
+    SDPA, then to_out) - a documented deviation whose distance from the reference order is measured in tests/test_dit_gpu.py."""
+    B, Nq, d = q.shape
+    hd = d // heads
+    r = lambda t: t.to(torch.bfloat16).float()
+    qh = r(q).view(B, Nq, heads, hd).transpose(1, 2)
+    kh = r(k).view(B, -1, heads, hd).transpose(1, 2)
+    vh = r(v).view(B, -1, heads, hd).transpose(1, 2)                                  # [B, H, Lk, hd]
+    s = qh @ kh.transpose(-1, -2) * torch.tensor(hd ** -0.5, dtype=torch.float32)
+    if key_bias is not None:
+        s = s + key_bias[:, None, None, :]
+    pr = r(torch.softmax(s, -1))                                                      # normalised probabilities, bf16
+    woh = r(wo.float()).view(d, heads, hd).permute(1, 2, 0)                           # [H, hd, d]
+    vwo = r(vh @ woh[None])                                                           # [B, H, Lk, d] = bf16(V_h Wo_h^T)
+    out = torch.einsum("bhqk,bhkn->bqn", pr, vwo)
+    return r(out + bo.float())
+
+
+def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gemm=False, flash=False, ctx_keys=None, fp16_norm=False,
+                  ctx_vo=False):
     """`flash`: attention with the HIP flash kernel's bf16-P rounding points; `ctx_keys` = (Lk, key_bias [B, Lk]) runs the cross-attention
     over the first Lk context rows with an additive key bias (the product's merged zero-padding key); `fp16_norm`:
     the reference loads fp16 weights (inference_t23d.py:73) and diffusers' RMSNorm casts its output to the weight dtype, i.e. q / k pass
@@ -248,7 +270,12 @@ def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gem
     kb = None
     if ctx_keys is not None:
         k, v, kb = k[:, :ctx_keys[0]], v[:, :ctx_keys[0]], ctx_keys[1]
-    a = _lin(attention(q, k, v, H, emu, flash, kb), sd, p + "attn2.to_out.0", emu, g8)
+    if ctx_vo and not g8:
+        if p + "attn2.to_out.0.lora_A.weight" in sd:
+            raise NotImplementedError("ctx_vo emulates the merged-weight product path: merge the adapter first")
+        a = cross_attention_ctx_vo(q, k, v, H, sd[p + "attn2.to_out.0.weight"], sd[p + "attn2.to_out.0.bias"], kb)
+    else:
+        a = _lin(attention(q, k, v, H, emu, flash, kb), sd, p + "attn2.to_out.0", emu, g8)
     x = _r(x + a, emu)
     # 3. feed forward
     n = _r(F.layer_norm(x.float(), (d,), eps=eps) * (1 + c_scale) + c_shift, emu)
@@ -292,11 +319,12 @@ def merged_padding_keys(text: torch.Tensor):
 def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.Tensor, timestep: torch.Tensor,
                 text: torch.Tensor, emulate_bf16: bool = False, num_layers: int | None = None, fp8_attn: bool = False,
                 fp8_gemm: bool = False, flash: bool = False, merge_padding: bool = False, fp16_norm: bool = False,
-                depth_outputs: dict | None = None) -> torch.Tensor:
+                depth_outputs: dict | None = None, ctx_vo: bool = False) -> torch.Tensor:
     """transformer(hidden_states[B,16,T,H,W], timestep[B], encoder_hidden_states[B,L,4096]) -> [B,16,T,H,W].
     `flash` / `merge_padding` switch on the two places where the HIP path's CONTRACT differs from exact softmax over all 512 context
     rows (bf16 P per 64-key tile; one merged zero-padding key) so that a full-depth comparison measures the kernels, not those.
-    `depth_outputs` = {L: None, ...}: filled with the model output truncated after L blocks (== num_layers=L), for error-vs-depth curves."""
+    `depth_outputs` = {L: None, ...}: filled with the model output truncated after L blocks (== num_layers=L), for error-vs-depth curves.
+    `ctx_vo`: the cross-attention in the product's cached-context form (cross_attention_ctx_vo) - its third contract difference."""
     emu = emulate_bf16
     ctx_keys = merged_padding_keys(text) if merge_padding else None
     B, C, Fr, Hh, Ww = latents.shape
@@ -314,7 +342,7 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.T
         return unpatchify(cfg, _lin(h, sd, "proj_out", emu), Fr, Hh, Ww)
 
     for i in range(L):
-        x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn, fp8_gemm, flash, ctx_keys, fp16_norm)
+        x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn, fp8_gemm, flash, ctx_keys, fp16_norm, ctx_vo)
         if depth_outputs is not None and (i + 1) in depth_outputs:
             depth_outputs[i + 1] = head(x)      # what dit_forward(num_layers=i+1) returns, from the one pass
     return head(x)

@@ -331,10 +331,11 @@ def test_full_depth_production_size_forward_matches_oracle(hip_lib, parity):
 
     def compute():
         ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
-        # the same forward with the two CONTRACT differences of the HIP path emulated as well: bf16 P per 64-key flash tile (every
-        # flash kernel has that term, the reference's SDPA included) and the merged zero-padding key of the cross-attention
+        # the same forward with the CONTRACT differences of the HIP path emulated as well: bf16 P per 64-key flash tile (every flash
+        # kernel has that term, the reference's SDPA included), the merged zero-padding key of the cross-attention, and the
+        # cross-attention's cached-context order of operations (ctx_vo)
         taps = {L: None for L in depths}
-        ref_c = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, depth_outputs=taps)
+        ref_c = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True, depth_outputs=taps)
         d = dict(ref=ref, ref_c=ref_c, ref_rms=ref.pow(2).mean().sqrt().item())
         d.update({f"depth{L}": taps[L] for L in depths})
         return d
@@ -446,6 +447,46 @@ def test_time_tables_bit_identical_at_production_width(hip_lib, width):
     assert tabs[3][1].stride(1) == 0 and tabs[3][1].shape == (2, 2, 6, cfg.dim)    # a view: nothing materialised per step / batch item
 
 
+def test_cached_context_cross_attention_matches_flash_form_and_oracle(hip_lib, parity):
+    """WanDiT.ctx_vo (default on): attn2 = sum_h softmax_h(q K^T) (V_h Wo_h^T) + bo with (V_h Wo_h^T) cached per prompt, against the
+    reference's order of operations (flash attention, then to_out: ctx_vo = False) at production width, B = 2, 4096 tokens, two
+    blocks, zero-padded 64 / 80-token prompts - and both against the oracle with the respective rounding points.  The two HIP forms must
+    be as close to each other as the oracle's two forms are (the deviation costs bf16 noise, nothing else), each within the two-block
+    tolerance of its own contract oracle."""
+    import dataclasses
+    from vist3a_amd.wan.dit import WAN_1_3B, WanDiT
+    cfg = dataclasses.replace(WAN_1_3B, num_layers=2, text_dim=512)
+    ocfg = O.WanDiTConfig(num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim, ffn_dim=cfg.ffn_dim,
+                          num_layers=2, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=21).items()}
+    model = WanDiT(cfg, sd, device="cuda")
+    assert model.ctx_vo
+    g = torch.Generator().manual_seed(22)
+    lat = torch.randn(2, 16, 4, 64, 64, generator=g).to(torch.bfloat16)
+    text = (torch.randn(2, 512, cfg.text_dim, generator=g) * 0.5).to(torch.bfloat16).float()
+    text[0, 64:] = 0
+    text[1, 80:] = 0
+    t = torch.tensor([650, 650])
+    out_vo = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
+    ent = next(iter(model._ctx.values()))[1]
+    assert ent[7] is not None and ent[8] == 96 and ent[5] == 88      # 88 merged keys per head, padded to 96: K = 12 x 96 = 1152
+    model.ctx_vo = False
+    model._ctx.clear()
+    out_fl = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
+    assert next(iter(model._ctx.values()))[1][7] is None
+    model.ctx_vo = True
+    with torch.no_grad():
+        ref_vo = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True)
+        ref_fl = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True)
+    r = dict(hip_vo_vs_oracle_vo=_rel(out_vo, ref_vo), hip_flash_vs_oracle_flash=_rel(out_fl, ref_fl), hip_vo_vs_hip_flash=_rel(out_vo, out_fl),
+             oracle_vo_vs_oracle_flash=_rel(ref_vo, ref_fl), hip_vo_vs_oracle_flash=_rel(out_vo, ref_fl))
+    parity("dit_cached_context_cross_attention_two_blocks", **r)
+    print("cached-context cross-attention (1.3B width, B = 2, N = 4096, 2 blocks):", {k: f"{v:.2e}" for k, v in r.items()})
+    assert torch.isfinite(out_vo).all()
+    assert r["hip_vo_vs_oracle_vo"] < 2 * TOL_ONE_BLOCK and r["hip_flash_vs_oracle_flash"] < 2 * TOL_ONE_BLOCK, r
+    assert r["hip_vo_vs_hip_flash"] < 2.0 * max(r["oracle_vo_vs_oracle_flash"], 1e-3), r
+
+
 def test_config4_wan14b_two_blocks_at_4096_tokens_matches_oracle(hip_lib, parity):
     """BASELINE config #4 AT SIZE: Wan-14B width (40 heads x 128 = 5120, FFN 13824), the CFG pair (B = 2) of a 13-view scene
     (N = 4096 tokens, M = 8192 GEMM rows: the ragged 5120 / 13824 tilings at their real M), 512-row zero-padded prompts - two blocks
@@ -471,9 +512,9 @@ def test_config4_wan14b_two_blocks_at_4096_tokens_matches_oracle(hip_lib, parity
     torch.cuda.synchronize()
     t0 = time.time()
     with torch.no_grad():
-        ref16 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True)
+        ref16 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True)
         t1 = time.time()
-        ref8 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, flash=True, merge_padding=True, num_layers=1)
+        ref8 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, flash=True, merge_padding=True, ctx_vo=True, num_layers=1)
     t2 = time.time()
     r16, r8, shift = _rel(out16, ref16), _rel(out8, ref8), _rel(out8, out16_1)
     parity("dit_config4_14B_N4096_B2_two_blocks", rel_bf16_vs_contract_oracle=r16, rel_fp8_attention_vs_e4m3_oracle=r8,

@@ -178,7 +178,7 @@ def test_config3_21_view_dit_forward_matches_oracle(hip_lib, parity):
     out = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
     torch.cuda.synchronize()
     with torch.no_grad():
-        ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True)
+        ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True)
     r = _rel(out, ref)
     parity("dit_config3_N6144_two_blocks", rel_vs_contract_oracle=r)
     print(f"config #3 DiT (N=6144, 2 blocks): rel vs contract oracle {r:.2e}")

@@ -784,3 +784,75 @@ def test_layernorm_fp8_output_equals_separate_quantisation_pass(hip_lib):
             s = torch.empty(M, device=dev)
             ops.layernorm(x, out=q, fp8_scale=s, eps=1e-6, **kw)
             assert torch.equal(s, s_ref) and torch.equal(q, q_ref), (M, d, list(kw))
+
+
+# ---------------------------------------------------------------- cached-context cross-attention (csrc/xattn_probs.hip) ----
+XATTN_CASES = [
+    ("dit_1_3b_88_keys", 2, 12, 4096, 88, 96, True),      # production: 80 / 64 real tokens + merged padding key, padded to 96 per head
+    ("one_key_tile", 2, 12, 1000, 40, 48, True),          # <= 64 keys: the one-tile instantiation; ragged last query block
+    ("full_128_keys", 1, 40, 512, 128, 128, False),       # Wan-14B head count, both key tiles full, no bias
+    ("two_heads_pad32", 2, 2, 96, 24, 32, True),          # the test models' geometry (H = 2: keys padded to 32 so that H * Lkp % 64 == 0)
+]
+
+
+@pytest.mark.parametrize("name,B,H,Nq,Nk,Lkp,biased", XATTN_CASES, ids=[c[0] for c in XATTN_CASES])
+def test_xattn_probs_matches_fp32_softmax(hip_lib, parity, name, B, H, Nq, Nk, Lkp, biased):
+    """v3a_xattn_probs_bf16: P[m, h * Lkp + j] = bf16(softmax_j(q_h . k_hj / sqrt(128) + bias_j)) for j < Nk, exact zeros in the padding
+    columns, rows of every head summing to 1 within bf16 rounding; against fp32 softmax evaluated by torch on the same bf16 q, k."""
+    from vist3a_amd import ops
+    D = 128
+    g = torch.Generator(device=dev).manual_seed(Nk * 7 + H)
+    q = torch.randn(B * Nq, H * D, device=dev, generator=g).to(bf16)
+    Lt = Nk + 5                                            # the key buffer has more rows than keys (row stride of the batch item)
+    k = torch.randn(B * Lt, H * D, device=dev, generator=g).to(bf16)
+    bias = None
+    if biased:
+        bias = torch.zeros(B, 128, device=dev)
+        bias[:, Nk - 1] = math.log(512 - (Nk - 1))         # the merged zero-padding key
+    Kp = H * Lkp
+    out = torch.full((B * Nq, Kp + 8), 7.0, device=dev, dtype=bf16)   # row stride > H * Lkp; the guard columns must stay untouched
+    p = out[:, :Kp]
+    ops.xattn_probs(q, k, p, B=B, H=H, Nq=Nq, Nk=Nk, Lkp=Lkp, q_batch_stride=Nq * H * D, k_batch_stride=Lt * H * D,
+                    p_batch_stride=Nq * (Kp + 8), key_bias=bias, key_bias_first=Nk - 1)
+    torch.cuda.synchronize()
+    qf = q.float().view(B, Nq, H, D).transpose(1, 2)
+    kf = k.float().view(B, Lt, H, D)[:, :Nk].transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2) * D ** -0.5
+    if bias is not None:
+        s = s + bias[:, None, None, :Nk]
+    ref = torch.softmax(s, -1)                              # [B, H, Nq, Nk] fp32
+    got = p.float().view(B, Nq, H, Lkp).permute(0, 2, 1, 3)
+    assert torch.equal(out[:, Kp:], torch.full_like(out[:, Kp:], 7.0))
+    assert (got[..., Nk:] == 0).all()
+    r = ((got[..., :Nk] - ref).norm() / ref.norm()).item()
+    exact = (got[..., :Nk] == ref.to(bf16).float()).float().mean().item()   # share of elements that ARE the correctly rounded fp32 value
+    rowsum = (got.sum(-1) - 1).abs().max().item()
+    parity("xattn_probs", name=name, rel_vs_fp32=r, correctly_rounded_share=exact, max_rowsum_error=rowsum)
+    assert r < 3e-3 and exact > 0.97 and rowsum < 8e-3, (r, exact, rowsum)   # measured: rel ~1.7e-3 = the bf16 rounding of P itself
+
+
+def test_gemm_batched_operands_equal_separate_launches(hip_lib):
+    """v3a_gemm_args.batch: `batch` equally shaped problems in one launch (per-head / per-prompt operands) == the same problems launched one
+    by one, bit for bit, with bias + residual epilogue, for a ping-pong tile shape and for the tiny per-head V.Wo^T shape."""
+    from vist3a_amd import ops
+    g = torch.Generator(device=dev).manual_seed(77)
+    # (1) two CFG items, one B operand each: [4096, 1152] x [1536, 1152]^T + bias + residual (the cross-attention's finishing GEMM)
+    nb, M, N, K = 2, 4096, 1536, 1152
+    a = torch.randn(nb * M, K, device=dev, generator=g).to(bf16)
+    w = (torch.randn(nb, N, K, device=dev, generator=g) / math.sqrt(K)).to(bf16)
+    bias = torch.randn(N, device=dev, generator=g)
+    x = torch.randn(nb * M, N, device=dev, generator=g).to(bf16)
+    want = torch.cat([ops.gemm(a[z * M:(z + 1) * M], w[z], bias, residual=x[z * M:(z + 1) * M]) for z in range(nb)], 0)
+    got = x.clone()
+    ops.gemm(a[:M], w[0], bias, out=got[:M], residual=got[:M], batch=(nb, M * K, N * K, M * N))
+    assert torch.equal(got, want)
+    # (2) twelve heads: out[:, h * 96:(h + 1) * 96] = Wo[:, h-th 128 columns] . V[:, h-th 128 columns]^T  (column-offset strides, ldc = 12 * 96)
+    H, d, Lkp = 12, 1536, 96
+    wo = torch.randn(d, d, device=dev, generator=g).to(bf16)
+    v = torch.randn(Lkp, d, device=dev, generator=g).to(bf16)
+    out = torch.zeros(d, H * Lkp, device=dev, dtype=bf16)
+    ops.gemm(wo[:, :128], v[:, :128], out=out[:, :Lkp], batch=(H, 128, 128, Lkp))
+    ref = torch.cat([(wo[:, h * 128:(h + 1) * 128].float() @ v[:, h * 128:(h + 1) * 128].float().t()).to(bf16) for h in range(H)], 1)
+    one = torch.cat([ops.gemm(wo[:, h * 128:(h + 1) * 128], v[:, h * 128:(h + 1) * 128]) for h in range(H)], 1)
+    assert torch.equal(out, one)
+    assert ((out.float() - ref.float()).norm() / ref.float().norm()).item() < 3e-3

@@ -117,6 +117,11 @@ def test_merged_padding_key_is_exact_and_option_switches_compose():
     emu = O.dit_forward(sd, cfg, lat, t, text, emulate_bf16=True)
     assert rel(O.dit_forward(sd, cfg, lat, t, text, emulate_bf16=True, flash=True, merge_padding=True), emu) < 1e-2
     assert rel(O.dit_forward(sd, cfg, lat, t, text, emulate_bf16=True, fp16_norm=True), emu) < 5e-3
+    # the cached-context cross-attention (ctx_vo: sum_h bf16(P_h) bf16(V_h Wo_h^T)) is the same map with other rounding points: as far
+    # from the fp32 forward as the reference order of operations is, and within bf16 noise of it
+    con = O.dit_forward(sd, cfg, lat, t, text, emulate_bf16=True, flash=True, merge_padding=True)
+    vo = O.dit_forward(sd, cfg, lat, t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True)
+    assert rel(vo, con) < 4e-3 and rel(vo, full) < 1.3 * rel(con, full) + 1e-4
 
 
 def test_unmerged_lora_equals_merged_weights_in_fp32():

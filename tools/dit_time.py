@@ -9,6 +9,9 @@ from vist3a_amd.wan.weights import random_dit_state_dict
 cfg = WAN_1_3B
 sd = random_dit_state_dict(cfg, seed=0, device="cuda")
 m = WanDiT(cfg, sd)
+import os
+if os.environ.get('V3A_CTX_VO') == '0':
+    m.ctx_vo = False   # A/B: flash cross-attention + to_out GEMM instead of the cached-context form
 del sd
 Tl = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 lat = torch.randn(2, 16, Tl, 64, 64, device="cuda").bfloat16()

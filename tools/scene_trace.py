@@ -23,6 +23,14 @@ if len(sys.argv) > 2 and sys.argv[1] == "--report":
     print(json.dumps(dict(kernels=len(sel), busy_ms=round(busy / 1e3, 2), span_ms=round((sel[-1][1] - sel[0][0]) / 1e6, 2),
                           glue_launches=sum(len(v) for v in glue.values()), glue_ms=round(sum(sum(v) for v in glue.values()) / 1e3, 3),
                           glue_share_pct=round(100 * sum(sum(v) for v in glue.values()) / busy, 3))))
+    # the longest individual glue launches, with the library kernel that ran just before each (locates the call site)
+    idx = {id(r): i for i, r in enumerate(sel)}
+    big = sorted((r for r in sel if not ours(r[2].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))),
+                 key=lambda r: r[0] - r[1])[:25]
+    for r in big:
+        i = idx[id(r)]
+        prev = next((sel[j][2] for j in range(i - 1, -1, -1) if ours(sel[j][2].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))), "-")
+        print(f"GLUE {(r[1] - r[0]) / 1e3:8.1f} us  {r[2][:70]:70s} after {prev[:60]}")
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[: int(sys.argv[3]) if len(sys.argv) > 3 else 60]:
         print(f"{'  ' if ours(k) else 'G '}{k:112s} n {len(v):5d} avg_us {sum(v) / len(v):9.1f} max_us {max(v):9.1f} sum_ms {sum(v) / 1e3:9.3f} {100 * sum(v) / busy:6.3f}%")
     sys.exit(0)

@@ -56,7 +56,7 @@ struct TileCfg {
 template <int BM, int BN, int WM, int WN, int BK, int NS, bool CONV, int STG>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel(const GemmP pin) {
   GemmP p = pin;
-  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; }
+  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; if (p.res) p.res += blockIdx.y * p.rz; }
   using T = TileCfg<BM, BN, WM, WN, BK, NS>;
   constexpr int NW = T::NW, MT = T::MT, NTL = T::NTL, NL = T::NL, STAGE = T::STAGE;
   constexpr int WTM = T::WTM, WTN = T::WTN, PITCH = T::PITCH;
@@ -361,7 +361,7 @@ constexpr int ABL = V3A_GEMM_ABL;
 template <int NP, bool RA, int LEAD, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP pin) {
   GemmP p = pin;
-  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; }
+  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; if (p.res) p.res += blockIdx.y * p.rz; }
   using T = PPCfg<NP>;
   constexpr int RB = T::RB, STAGE = T::STAGE, J = T::J;
   constexpr int BM = RA ? 256 : 64 * NP, BN = RA ? 64 * NP : 256;
@@ -854,7 +854,14 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   p.res2 = (const char*)a->residual2; p.ldr2 = a->ldr2; p.res_mod = a->res_row_mod;
   p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
   if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
-  if (a->split_k < 0) return V3A_ERR_ARG;
+  if (a->split_k < 0 || a->batch < 0 || (a->batch > 1 && a->split_k > 1) || a->batch > 65535) return V3A_ERR_ARG;
+  if (a->batch > 1) {     // equally shaped problems side by side on blockIdx.y (per-head / per-prompt operands)
+    if (a->a_batch_stride % 8 || a->b_batch_stride % 8 || a->c_batch_stride % 8 || a->res_batch_stride % 8) return V3A_ERR_SHAPE;
+    p.az = a->a_batch_stride * 2; p.bz = a->b_batch_stride * 2;
+    p.cz = a->c_batch_stride * ((a->flags & V3A_GEMM_OUT_F32) ? 4 : 2);
+    p.rz = a->res_batch_stride * ((a->flags & V3A_GEMM_RES_F32) ? 4 : 2);
+    return launch(p, a->tile, false, stream, a->batch);
+  }
   if (a->split_k > 1) {   // S equally long K slices side by side (blockIdx.y), bf16 partials, then the epilogue in a second launch
     const int S = a->split_k;
     if (!a->workspace || a->K % (64 * S)) return V3A_ERR_ARG;

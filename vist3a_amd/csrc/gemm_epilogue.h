@@ -31,8 +31,8 @@ struct GemmP {
   // e4m3 operands (gemm_pp_kernel<.., F8 = true> only): per-row dequantisation scales of A and B (fp32), applied to the accumulators
   const float* a_scale;   // [M]
   const float* b_scale;   // [N]
-  // blockIdx.y = z selects one of several equally shaped problems (split-K slices): byte offsets of A, B, C per z
-  long az, bz, cz;
+  // blockIdx.y = z selects one of several equally shaped problems (split-K slices, batched operands): byte offsets of A, B, C, res per z
+  long az, bz, cz, rz;
 };
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};

@@ -33,6 +33,8 @@ class GemmArgs(C.Structure):
         ("residual2", C.c_void_p), ("ldr2", C.c_int), ("res_row_mod", C.c_int),
         ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
         ("split_k", C.c_int), ("workspace", C.c_void_p),
+        ("batch", C.c_int), ("a_batch_stride", C.c_long), ("b_batch_stride", C.c_long), ("c_batch_stride", C.c_long),
+        ("res_batch_stride", C.c_long),
     ]
 
 
@@ -113,6 +115,16 @@ class AttnArgs(C.Structure):
     ]
 
 
+class XattnProbsArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("p", C.c_void_p), ("key_bias", C.c_void_p),
+        ("q_batch_stride", C.c_long), ("k_batch_stride", C.c_long), ("p_batch_stride", C.c_long),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldp", C.c_int),
+        ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int), ("Lkp", C.c_int),
+        ("key_bias_stride", C.c_int), ("key_bias_first", C.c_int), ("scale", C.c_float),
+    ]
+
+
 class GemmFp8Args(C.Structure):
     _fields_ = [("g", GemmArgs), ("a_scale", C.c_void_p), ("b_scale", C.c_void_p)]
 
@@ -177,6 +189,7 @@ SYMBOLS = {
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_conv_halo_tiles": (C.c_long, [C.POINTER(ConvArgs)]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
+    "v3a_xattn_probs_bf16": (C.c_int, [C.POINTER(XattnProbsArgs), C.c_void_p]),
     "v3a_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "v3a_unipc_cfg_step": (C.c_int, [C.POINTER(UniPCStepArgs), C.c_void_p]),
     "v3a_attention_fwd_fp8": (C.c_int, [C.POINTER(AttnFp8Args), C.c_void_p]),
@@ -213,7 +226,7 @@ SYMBOLS = {
 }
 
 _lib = None
-EXPECTED_ABI = 17   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
+EXPECTED_ABI = 18   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
 
 
 class HipLibraryError(RuntimeError):

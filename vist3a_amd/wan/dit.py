@@ -100,6 +100,7 @@ class _Workspace:
         self.x = e(M, d)
         self.n = e(M, d)
         self.q2 = e(M, d)
+        self.p2 = None     # cross-attention probabilities [M, heads * padded keys] of the cached-context form, allocated on first use
         self.ao = e(M, d)
         self.h = e(M, cfg.ffn_dim)
         self.tok = e(M, cfg.in_channels * math.prod(cfg.patch_size))
@@ -143,6 +144,11 @@ class WanDiT:
         # v3a_attention_fwd_bf16; deterministic, within bf16 rounding of the unsharded forward) and split the K of its FFN2 GEMM;
         # 1 = never (bit-identical to the unsharded forward).
         self.sp_kv_split: Optional[int] = None
+        # Cross-attention in its cached-context form  attn2(x) = sum_h softmax_h(q K^T) (V_h Wo_h^T) + bo  (csrc/xattn_probs.hip): K, V
+        # depend on the prompt only, so (V_h Wo_h^T) is built once per prompt in `_context`; per step one probabilities kernel and ONE GEMM
+        # with K = heads * padded keys (1152 at Wan-1.3B) replace the flash kernel's P.V MFMAs and the K = d to_out projection.  Taken when
+        # head_dim = 128, the (merged) key count is <= 128 and the block GEMMs run in bf16; False = flash attention + to_out GEMM.
+        self.ctx_vo = True
         self._load(state_dict)
 
     def _sp_ksplit(self, M: int, N: int, K: int) -> int:
@@ -235,12 +241,15 @@ class WanDiT:
         cfg = self.cfg
         d = cfg.dim
         Lp = (Lt + 63) // 64 * 64
+        H, hd = cfg.num_attention_heads, cfg.attention_head_dim
         if ent is None:
             ks = [torch.empty(B * Lt, d, device=self.device, dtype=bf16) for _ in self.blocks]
             vts = [torch.zeros(d, B * Lp, device=self.device, dtype=bf16) for _ in self.blocks]
             kbias = torch.zeros(B, Lp, device=self.device, dtype=f32)
+            # [B, d, H * 128] per block: (V_h Wo_h^T) of the cached-context form, viewed [B, d, H * Lkp] for the prompt's key count
+            vwo_store = [torch.empty(B * d * H * 128, device=self.device, dtype=bf16) for _ in self.blocks] if (self.ctx_vo and hd == 128) else None
         else:
-            ks, vts, kbias = ent[1][0], ent[1][1], ent[1][4]
+            ks, vts, kbias, vwo_store = ent[1][0], ent[1][1], ent[1][4], ent[1][9]
         # trailing all-zero rows (one host sync per prompt)
         nz = (text != 0).any(dim=-1)                                   # [B, Lt]
         last = torch.where(nz.any(dim=1), Lt - 1 - nz.flip(1).float().argmax(dim=1), torch.full((B,), -1, device=text.device))
@@ -262,7 +271,21 @@ class WanDiT:
                 ops.rmsnorm_rope(k[rows], b["nk2"], out=k[rows], eps=cfg.eps)
                 # V^T per batch item so each lands at its 64-padded column block
                 ops.gemm(b["wv2"], c[rows], b["bv2"], out=vt[:, bi * Lp: bi * Lp + Lk], bias_row=True)
-        self._ctx[slot] = (key, (ks, vts, Lt, Lp, kbias, Lk, merged))
+        # cached-context cross-attention: V rows [Lkp, d] (zero past Lk) -> VWo[b][n, h * Lkp + j] = sum_c Wo[n, h hd + c] V[j, h hd + c],
+        # one batched GEMM over the heads per (block, batch item); fp32 accumulation, rounded to bf16 once
+        vwos, Lkp = None, 0
+        gran = max(16, 64 // math.gcd(H, 64))    # keys per head padded so that the GEMM's K = H * Lkp is a multiple of 64 (16 at 12 / 40 heads)
+        if vwo_store is not None and (Lk + gran - 1) // gran * gran <= 128:
+            Lkp = (Lk + gran - 1) // gran * gran
+            Kp = H * Lkp
+            vrow = torch.zeros(B * Lkp, d, device=self.device, dtype=bf16)
+            vwos = [st[: B * d * Kp].view(B, d, Kp) for st in vwo_store]
+            for b, vwo in zip(self.blocks, vwos):
+                for bi in range(B):
+                    vr = vrow[bi * Lkp: bi * Lkp + Lk]
+                    ops.gemm(c[bi * Lt: bi * Lt + Lk], b["wv2"], b["bv2"], out=vr)
+                    ops.gemm(b["wo2"][:, :hd], vrow[bi * Lkp:(bi + 1) * Lkp, :hd], out=vwo[bi][:, :Lkp], batch=(H, hd, hd, Lkp))
+        self._ctx[slot] = (key, (ks, vts, Lt, Lp, kbias, Lk, merged, vwos, Lkp, vwo_store))
         return self._ctx[slot][1]
 
     # ---------------------------------------------------------------- forward
@@ -292,7 +315,7 @@ class WanDiT:
         if rope is None:
             rope = self._rope[(ppf, pph, ppw)] = rope_table(cfg, ppf, pph, ppw, self.device)
         rope = rope[rk * Nl:(rk + 1) * Nl]
-        ks, vts, Lt, Lp, kbias, Lk, merged = self._context(encoder_hidden_states)
+        ks, vts, Lt, Lp, kbias, Lk, merged, vwos, Lkp, _ = self._context(encoder_hidden_states)
 
         # patchify: Conv3d(k=s=(1,2,2)) == GEMM over (c,pt,ph,pw)-major patches
         if not tokens_in:
@@ -433,11 +456,21 @@ class WanDiT:
             norm(weight=b["n2w"], bias=b["n2b"])
             lin(ws.n, b, "wq2", b["bq2"], out=ws.q2)
             ops.rmsnorm_rope(ws.q2, b["nq2"], out=ws.q2, eps=cfg.eps)
-            ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lk, D=hd, q_batch_stride=Nl * d,
-                          k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d, key_bias=kbias if merged else None,
-                          key_bias_first=Lk - 1)
-            lin.last = None
-            lin(ws.ao, b, "wo2", b["bo2"], out=x, residual=x)
+            if vwos is not None and not g8:
+                # cached-context form: probabilities [B Nl, H Lkp], then ONE GEMM against the prompt's (V_h Wo_h^T), one B operand per batch item
+                Kp = H * Lkp
+                if ws.p2 is None:
+                    ws.p2 = torch.empty(Ml * H * 128, device=self.device, dtype=bf16)
+                p2 = ws.p2[: Ml * Kp].view(Ml, Kp)
+                ops.xattn_probs(ws.q2, ks[li], p2, B=B, H=H, Nq=Nl, Nk=Lk, Lkp=Lkp, q_batch_stride=Nl * d, k_batch_stride=Lt * d,
+                                p_batch_stride=Nl * Kp, key_bias=kbias if merged else None, key_bias_first=Lk - 1)
+                ops.gemm(p2[:Nl], vwos[li][0], b["bo2"], out=x[:Nl], residual=x[:Nl], batch=(B, Nl * Kp, d * Kp, Nl * d))
+            else:
+                ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lk, D=hd, q_batch_stride=Nl * d,
+                              k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d, key_bias=kbias if merged else None,
+                              key_bias_first=Lk - 1)
+                lin.last = None
+                lin(ws.ao, b, "wo2", b["bo2"], out=x, residual=x)
             # --- feed forward
             norm(scale=m[:, 4], shift=m[:, 3], rows_per_batch=Nl)
             lin(ws.n, b, "w1", b["b1"], out=ws.h, act=L.ACT_GELU_TANH)
