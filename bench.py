@@ -118,10 +118,15 @@ def cpu_baseline(cfg, mode: str, repeats: int = 3, dit_blocks: int = 6):
                                   "note": "BASELINE config #1 (10 denoise steps) = 20 x DiT + decode + recon"})
 
 
-def dit_flops_executed(N, d, ffn, L, ctx_keys: int):
+def dit_flops_executed(N, d, ffn, L, ctx_keys: int, heads_x_padded_keys: int = 0):
     """FLOPs the product actually executes per forward: the text context K / V^T projections are cached per prompt (not per step),
-    and cross-attention runs over the `ctx_keys` real + merged-padding keys instead of 512."""
-    return L * (8 * N * d * d + 4 * N * N * d + 4 * N * d * d + 4 * N * ctx_keys * d + 4 * N * d * ffn)
+    and cross-attention runs over the `ctx_keys` real + merged-padding keys instead of 512.  `heads_x_padded_keys` > 0: the
+    cached-context form (WanDiT.ctx_vo) - to_q, scores, then one GEMM with K = heads x padded keys instead of P.V + the to_out GEMM."""
+    if heads_x_padded_keys:
+        cross = 2 * N * d * d + 2 * N * ctx_keys * d + 2 * N * heads_x_padded_keys * d
+    else:
+        cross = 4 * N * d * d + 4 * N * ctx_keys * d
+    return L * (8 * N * d * d + 4 * N * N * d + cross + 4 * N * d * ffn)
 
 
 def coop_requested(a, world):
@@ -324,6 +329,9 @@ def main():
         ach = ps["flops_per_launch"] / (ps["avg_ms"] * 1e-3) / 1e12 if ps["launches"] else 0.0
         fwd_flops = dit_flops_per_forward(N, cfg.dim, cfg.ffn_dim, cfg.num_layers)
         ctx_keys = (64 + 1 + 80 + 1) // 2   # synthetic prompts: 64 / 80 real tokens + one merged padding key each (cond / uncond)
+        tr = model.transformer
+        ent = next(iter(tr._ctx.values()))[1] if getattr(tr, "_ctx", None) else None
+        hxk = cfg.num_attention_heads * ent[8] if (ent is not None and ent[7] is not None) else 0   # cached-context form active: heads x padded keys
         U = int(out.gaussians.means.shape[1])
         dom_symbol = SYMBOL_OF_TILE.get(lib.load().v3a_gemm_tile_name(dom_tile).decode()) if not f8 else None
         traffic, traffic_src = (None, "fp8 mode: not profiled") if f8 else (pmc_traffic(dom_symbol) if dom_symbol else (None, "unknown tile symbol"))
@@ -353,10 +361,11 @@ def main():
                        "recon_tail_on_spread_cloud (untimed extra)": tail,
                        "box_speed_probe (untimed extra)": box,
                        "dit_model_tflops_per_s": round(2 * a.denoise_steps * fwd_flops / (stage.denoise_ms * 1e-3) / 1e12, 1),
-                       "dit_executed_tflops_per_s": round(2 * a.denoise_steps * dit_flops_executed(N, cfg.dim, cfg.ffn_dim, cfg.num_layers, ctx_keys)
+                       "dit_executed_tflops_per_s": round(2 * a.denoise_steps * dit_flops_executed(N, cfg.dim, cfg.ffn_dim, cfg.num_layers, ctx_keys, hxk)
                                                           / (stage.denoise_ms * 1e-3) / 1e12, 1),
                        "dit_flops_note": f"model = BASELINE.md §2 formula (512 text keys, context K/V projected every step); executed = "
-                                         f"{ctx_keys} cross-attention keys after merging the zero-padding keys, context K/V cached per prompt"},
+                                         f"{ctx_keys} cross-attention keys after merging the zero-padding keys, context K/V cached per prompt"
+                                         + (f", cross-attention in the cached-context form (to_out folded into a per-prompt V.Wo^T: one GEMM with K = {hxk})" if hxk else "")},
             "roofline": {"bound": "mfma",
                          "kernel": (f"gemm_pp_kernel<.., F8> = tile {lib.load().v3a_gemm_fp8_tile_name(dom_tile).decode()} (e4m3 MFMA 32x32x64 f8f6f4, ping-pong)" if f8 else
                                     f"{dom_symbol} = tile {lib.load().v3a_gemm_tile_name(dom_tile).decode()} (bf16 MFMA 32x32x16, ping-pong 256x192)"),

@@ -79,6 +79,11 @@ typedef struct {
                          * shared.  Used for per-head and per-prompt operands (the cached-context cross-attention of the DiT: one B
                          * operand per CFG batch item) where separate launches would each fill a fraction of the chip. */
   long a_batch_stride, b_batch_stride, c_batch_stride, res_batch_stride;
+  float* row_sumsq;     /* optional by-product (v3a_gemm_bf16_nt; N % 32 == 0, act NONE, no scale, no BIAS_ROW, no split_k): f32 [M][N / 32],
+                         * entry [m][n / 32] = sum over the 32-column block of bf16(acc + bias)^2 - the statistics of an RMS norm that the
+                         * CONSUMER applies (v3a_xattn_probs_args.q_row_sumsq), so the normalisation pass over the output disappears.
+                         * Independent of the tile shape (bit-identical for every tile); with `batch` the rows of problem z are
+                         * offset by z * M. */
 } v3a_gemm_args;
 int v3a_gemm_bf16_nt(const v3a_gemm_args* args, void* stream);
 size_t v3a_gemm_split_workspace_bytes(int M, int N, int split_k);
@@ -200,6 +205,12 @@ typedef struct {
   int B, H, Nq, Nk, D, Lkp;
   int key_bias_stride, key_bias_first;
   float scale;
+  const float* q_row_sumsq;   /* optional: q is NOT yet RMS-normalised; f32 [B * Nq rows of q][q_sumsq_parts] partial sums of squares of each
+                               * full q row (v3a_gemm_args.row_sumsq of the projection that produced q: parts = H * D / 32).  The kernel
+                               * multiplies the scores of query m by rsqrt(sum(parts) / (H * D) + q_eps) - the per-row factor of
+                               * diffusers' RMSNorm "across heads"; its per-column weight must be folded into k by the caller. */
+  int q_sumsq_parts;
+  float q_eps;
 } v3a_xattn_probs_args;
 int v3a_xattn_probs_bf16(const v3a_xattn_probs_args* args, void* stream);
 

@@ -206,18 +206,23 @@ def condition_embed(sd, cfg, timestep, text, emu):
     return temb, tproj, ctx
 
 
-def cross_attention_ctx_vo(q, k, v, heads, wo, bo, key_bias=None):
+def cross_attention_ctx_vo(q_raw, gq, k, v, heads, wo, bo, eps, key_bias=None):
     """Rounding points of the product's cached-context cross-attention (vist3a_amd/wan/dit.py `ctx_vo`, csrc/xattn_probs.hip):
-        attn2 = sum_h bf16(softmax_h(q K^T)) . bf16(bf16(V_h) Wo_h^T) + bo        (fp32 accumulation, one bf16 rounding of the result)
-    instead of  bf16(softmax(q K^T) V) Wo^T + bo.  Equal in real arithmetic; NOT the reference's order of operations (diffusers runs
-    SDPA, then to_out) - a documented deviation whose distance from the reference order is measured in tests/test_dit_gpu.py."""
-    B, Nq, d = q.shape
+        attn2 = sum_h bf16(softmax_h(r_q (q K''^T))) . bf16(bf16(V_h) Wo_h^T) + bo        (fp32 accumulation, one bf16 rounding of the result)
+    instead of  bf16(softmax(RMSNorm(q) K^T) V) Wo^T + bo, where q is the to_q projection's own bf16 output (NOT normalised, not rounded
+    again), r_q = rsqrt(mean(q^2) + eps) its RMS factor applied to the fp32 scores, and K'' = bf16(K (.) norm_q.weight) the cached
+    (already normalised, bf16) keys with the query norm's per-column weight folded in.  Equal in real arithmetic; NOT the reference's
+    order of operations (diffusers: RMSNorm(q), SDPA, to_out) - a documented deviation whose distance from the reference order is
+    measured in tests/test_dit_gpu.py."""
+    B, Nq, d = q_raw.shape
     hd = d // heads
     r = lambda t: t.to(torch.bfloat16).float()
-    qh = r(q).view(B, Nq, heads, hd).transpose(1, 2)
-    kh = r(k).view(B, -1, heads, hd).transpose(1, 2)
+    qb = r(q_raw)
+    rq = torch.rsqrt(qb.pow(2).mean(-1, keepdim=True) + eps)                          # [B, Nq, 1] fp32
+    qh = qb.view(B, Nq, heads, hd).transpose(1, 2)
+    kh = r(r(k) * gq.float()).view(B, -1, heads, hd).transpose(1, 2)
     vh = r(v).view(B, -1, heads, hd).transpose(1, 2)                                  # [B, H, Lk, hd]
-    s = qh @ kh.transpose(-1, -2) * torch.tensor(hd ** -0.5, dtype=torch.float32)
+    s = qh @ kh.transpose(-1, -2) * (rq[:, None] * torch.tensor(hd ** -0.5, dtype=torch.float32))
     if key_bias is not None:
         s = s + key_bias[:, None, None, :]
     pr = r(torch.softmax(s, -1))                                                      # normalised probabilities, bf16
@@ -264,7 +269,8 @@ def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gem
     x = _r(x.float() + a * gate_msa, emu)
     # 2. cross attention (norm2 has affine, no modulation; no mask over zero-padded text rows)
     n = _r(F.layer_norm(x.float(), (d,), sd[p + "norm2.weight"].float(), sd[p + "norm2.bias"].float(), eps), emu)
-    q = h16(rms_norm(_lin(n, sd, p + "attn2.to_q", emu, g8), sd[p + "attn2.norm_q.weight"], eps))
+    q_raw = _lin(n, sd, p + "attn2.to_q", emu, g8)
+    q = h16(rms_norm(q_raw, sd[p + "attn2.norm_q.weight"], eps))
     k = h16(rms_norm(_lin(ctx, sd, p + "attn2.to_k", emu), sd[p + "attn2.norm_k.weight"], eps))
     v = _lin(ctx, sd, p + "attn2.to_v", emu)
     kb = None
@@ -273,7 +279,8 @@ def block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn=False, fp8_gem
     if ctx_vo and not g8:
         if p + "attn2.to_out.0.lora_A.weight" in sd:
             raise NotImplementedError("ctx_vo emulates the merged-weight product path: merge the adapter first")
-        a = cross_attention_ctx_vo(q, k, v, H, sd[p + "attn2.to_out.0.weight"], sd[p + "attn2.to_out.0.bias"], kb)
+        a = cross_attention_ctx_vo(q_raw, sd[p + "attn2.norm_q.weight"], k, v, H, sd[p + "attn2.to_out.0.weight"], sd[p + "attn2.to_out.0.bias"],
+                                   eps, kb)
     else:
         a = _lin(attention(q, k, v, H, emu, flash, kb), sd, p + "attn2.to_out.0", emu, g8)
     x = _r(x + a, emu)

@@ -795,6 +795,28 @@ XATTN_CASES = [
 ]
 
 
+def test_gemm_row_sumsq_by_product_is_tile_independent(hip_lib):
+    """v3a_gemm_args.row_sumsq: per (row, 32-column block) sum of squares of bf16(acc + bias), emitted by the epilogue of every tile shape
+    with the same bits, and equal to the squares of the stored bf16 output summed in fp32."""
+    from vist3a_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    M, N, K = 8192, 1536, 1536
+    a = torch.randn(M, K, device=dev, generator=g).to(bf16)
+    w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).to(bf16)
+    bias = torch.randn(N, device=dev, generator=g)
+    names = _tile_names(hip_lib)
+    ref_sq = ref_out = None
+    for t in range(len(names)):
+        sq = torch.zeros(M, N // 32, device=dev)
+        out = ops.gemm(a, w, bias, tile=t, row_sumsq=sq)
+        if ref_sq is None:
+            ref_sq, ref_out = sq, out
+            want = out.float().view(M, N // 32, 32).pow(2).sum(-1)
+            assert ((sq - want).abs() / want).max().item() < 1e-5
+        assert torch.equal(out, ref_out) and torch.equal(sq, ref_sq), names[t]
+    assert torch.equal(ops.gemm(a, w, bias), ref_out)     # and the by-product does not disturb the output
+
+
 @pytest.mark.parametrize("name,B,H,Nq,Nk,Lkp,biased", XATTN_CASES, ids=[c[0] for c in XATTN_CASES])
 def test_xattn_probs_matches_fp32_softmax(hip_lib, parity, name, B, H, Nq, Nk, Lkp, biased):
     """v3a_xattn_probs_bf16: P[m, h * Lkp + j] = bf16(softmax_j(q_h . k_hj / sqrt(128) + bias_j)) for j < Nk, exact zeros in the padding
@@ -827,8 +849,23 @@ def test_xattn_probs_matches_fp32_softmax(hip_lib, parity, name, B, H, Nq, Nk, L
     r = ((got[..., :Nk] - ref).norm() / ref.norm()).item()
     exact = (got[..., :Nk] == ref.to(bf16).float()).float().mean().item()   # share of elements that ARE the correctly rounded fp32 value
     rowsum = (got.sum(-1) - 1).abs().max().item()
-    parity("xattn_probs", name=name, rel_vs_fp32=r, correctly_rounded_share=exact, max_rowsum_error=rowsum)
+    # q_row_sumsq: the same probabilities from an UN-normalised q plus its row statistics (the RMS factor applied to the scores)
+    qs = (q.float() * 3.0).to(bf16)                                               # rows with rms ~3
+    sq = qs.float().view(B * Nq, H * D // 32, 32).pow(2).sum(-1).contiguous()
+    eps = 1e-6
+    out2 = torch.zeros_like(out)
+    ops.xattn_probs(qs, k, out2[:, :Kp], B=B, H=H, Nq=Nq, Nk=Nk, Lkp=Lkp, q_batch_stride=Nq * H * D, k_batch_stride=Lt * H * D,
+                    p_batch_stride=Nq * (Kp + 8), key_bias=bias, key_bias_first=Nk - 1, q_row_sumsq=sq, q_eps=eps)
+    rq = torch.rsqrt(qs.float().pow(2).mean(-1) + eps).view(B, 1, Nq, 1)
+    s2 = (qs.float().view(B, Nq, H, D).transpose(1, 2) @ kf.transpose(-1, -2)) * rq * D ** -0.5
+    if bias is not None:
+        s2 = s2 + bias[:, None, None, :Nk]
+    ref2 = torch.softmax(s2, -1)
+    got2 = out2[:, :Kp].float().view(B, Nq, H, Lkp).permute(0, 2, 1, 3)
+    r2 = ((got2[..., :Nk] - ref2).norm() / ref2.norm()).item()
+    parity("xattn_probs", name=name, rel_vs_fp32=r, correctly_rounded_share=exact, max_rowsum_error=rowsum, rel_vs_fp32_folded_q_norm=r2)
     assert r < 3e-3 and exact > 0.97 and rowsum < 8e-3, (r, exact, rowsum)   # measured: rel ~1.7e-3 = the bf16 rounding of P itself
+    assert r2 < 3e-3 and (got2[..., Nk:] == 0).all(), r2
 
 
 def test_gemm_batched_operands_equal_separate_launches(hip_lib):

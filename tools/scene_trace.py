@@ -8,14 +8,14 @@ from pathlib import Path
 
 if len(sys.argv) > 2 and sys.argv[1] == "--report":
     f = glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True)[0]
-    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size_X", "?")) for r in csv.DictReader(open(f))))
     steps = [i for i, r in enumerate(rows) if "unipc_cfg_step_kernel" in r[2]]
     n = len(steps) // 2
     first, last = steps[n - 1] + 1, steps[-1] + 1
     sel = rows[first:last]
-    busy = sum(e - s for s, e, _ in sel) / 1e3
+    busy = sum(e - s for s, e, _, _g in sel) / 1e3
     acc = collections.defaultdict(list)
-    for s, e, nme in sel:
+    for s, e, nme, _g in sel:
         nme = nme.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
         acc[nme[:110]].append((e - s) / 1e3)
     ours = lambda k: not (k.startswith("void at::") or k.startswith("__amd_rocclr") or k.startswith("at::") or "rocprim" in k)
@@ -23,6 +23,14 @@ if len(sys.argv) > 2 and sys.argv[1] == "--report":
     print(json.dumps(dict(kernels=len(sel), busy_ms=round(busy / 1e3, 2), span_ms=round((sel[-1][1] - sel[0][0]) / 1e6, 2),
                           glue_launches=sum(len(v) for v in glue.values()), glue_ms=round(sum(sum(v) for v in glue.values()) / 1e3, 3),
                           glue_share_pct=round(100 * sum(sum(v) for v in glue.values()) / busy, 3))))
+    # glue launches inside the denoise loop (between two unipc steps) vs outside it, by (kernel, grid)
+    inner = collections.Counter()
+    for a, b in zip(steps[n:-1], steps[n + 1:]):
+        for r in rows[a + 1:b]:
+            k = r[2].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+            if not ours(k):
+                inner[(k[:60], r[3])] += 1
+    print("glue launches per denoise step (kernel, grid): ", {f"{k[0]} g{k[1]}": round(v / max(1, len(steps) - n - 1), 2) for k, v in inner.most_common(12)})
     # the longest individual glue launches, with the library kernel that ran just before each (locates the call site)
     idx = {id(r): i for i, r in enumerate(sel)}
     big = sorted((r for r in sel if not ours(r[2].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))),

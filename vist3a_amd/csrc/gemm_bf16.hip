@@ -56,7 +56,7 @@ struct TileCfg {
 template <int BM, int BN, int WM, int WN, int BK, int NS, bool CONV, int STG>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel(const GemmP pin) {
   GemmP p = pin;
-  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; if (p.res) p.res += blockIdx.y * p.rz; }
+  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; if (p.res) p.res += blockIdx.y * p.rz; if (p.rowsq) p.rowsq += (size_t)blockIdx.y * p.M * (p.N / 32); }
   using T = TileCfg<BM, BN, WM, WN, BK, NS>;
   constexpr int NW = T::NW, MT = T::MT, NTL = T::NTL, NL = T::NL, STAGE = T::STAGE;
   constexpr int WTM = T::WTM, WTN = T::WTN, PITCH = T::PITCH;
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel
   }
 
   gemm_add_bias<MT, NTL>(p, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
+  if constexpr (!CONV) gemm_row_sumsq<MT, NTL>(p, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
   gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8)>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
@@ -361,7 +362,7 @@ constexpr int ABL = V3A_GEMM_ABL;
 template <int NP, bool RA, int LEAD, bool F8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP pin) {
   GemmP p = pin;
-  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; if (p.res) p.res += blockIdx.y * p.rz; }
+  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; if (p.res) p.res += blockIdx.y * p.rz; if (p.rowsq) p.rowsq += (size_t)blockIdx.y * p.M * (p.N / 32); }
   using T = PPCfg<NP>;
   constexpr int RB = T::RB, STAGE = T::STAGE, J = T::J;
   constexpr int BM = RA ? 256 : 64 * NP, BN = RA ? 64 * NP : 256;
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP pin) {
     const int em = m0 + (RA ? wr * 64 : ws * 32 * NP), en = n0 + (RA ? ws * 32 * NP : wr * 64);
     if constexpr (F8) gemm_dequant<MT, NTL>(p, acc, lane, em, en);
     if constexpr (!(ABL & 32) && !(ABL & 128)) gemm_add_bias<MT, NTL>(p, acc, lane, em, en, aux);
+    gemm_row_sumsq<MT, NTL>(p, acc, lane, em, en);
     gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8), (ABL >> 4) & 15>(p, acc, smem, wave, lane, em, en, aux);
   }
 }
@@ -852,6 +854,10 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   p.rpb = a->rows_per_batch > 0 ? a->rows_per_batch : 1; p.sstride = a->scale_stride;
   p.act = a->act; p.flags = a->flags;
   p.res2 = (const char*)a->residual2; p.ldr2 = a->ldr2; p.res_mod = a->res_row_mod;
+  if (a->row_sumsq) {   // by-product of the plain bias epilogue only: the squares are those of bf16(acc + bias)
+    if (a->N % 32 || a->act != V3A_ACT_NONE || a->scale || a->split_k > 1 || (a->flags & V3A_GEMM_BIAS_ROW)) return V3A_ERR_ARG;
+    p.rowsq = a->row_sumsq;
+  }
   p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
   if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
   if (a->split_k < 0 || a->batch < 0 || (a->batch > 1 && a->split_k > 1) || a->batch > 65535) return V3A_ERR_ARG;

@@ -33,6 +33,7 @@ struct GemmP {
   const float* b_scale;   // [N]
   // blockIdx.y = z selects one of several equally shaped problems (split-K slices, batched operands): byte offsets of A, B, C, res per z
   long az, bz, cz, rz;
+  float* rowsq;           // optional by-product: sum of squares of every (row, 32-column block) of bf16(acc + bias), [M][N / 32] f32
 };
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -302,6 +303,31 @@ __device__ __forceinline__ void gemm_add_bias(const GemmP& p, f32x16 (&acc)[MT][
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[i][j][g * 4 + e] += bq[j][g][e];
   }
+}
+
+// By-product for a norm FOLDED into the consumer (v3a_gemm_args.row_sumsq): the sum of squares of the bf16-rounded outputs of every
+// (row, 32-column block) - rowsq[m * (N / 32) + n / 32], fp32.  Tile-shape independent: every wave tile is made of whole 32 x 32
+// blocks, and a block's 32 values are added in the same order by every tile (16 per lane half in accumulator order, then the two
+// halves), so the sequence-parallel forward (small tiles) and the unsharded one (ping-pong tiles) produce the same bits.
+template <int MT, int NTL>
+__device__ __forceinline__ void gemm_row_sumsq(const GemmP& p, const f32x16 (&acc)[MT][NTL], int lane, int mw0, int nw) {
+  if (!p.rowsq) return;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int nb = p.N / 32;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = round_bf16(acc[i][j][r]);
+        s = fmaf(v, v, s);
+      }
+      s += __shfl_xor(s, 32, 64);
+      const int m = mw0 + i * 32 + l31, n = nw + j * 32;
+      if (hi == 0 && m < p.M && n < p.N) p.rowsq[(size_t)m * nb + (n >> 5)] = s;
+    }
 }
 
 // the implicit-GEMM view of a convolution (M = output pixels, N = Cout, K = Kpad) + the epilogue operands

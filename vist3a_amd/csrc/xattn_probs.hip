@@ -12,8 +12,13 @@
 // the flash kernel's image: 256-byte rows, 16-byte chunks XOR-swizzled by row); S^T = K.Q^T on v_mfma_f32_32x32x16_bf16 with the
 // flash kernel's permuted key -> row map, so that lane (query = l31, hi) ends up with 16 CONSECUTIVE keys per 32-key sub-tile: the
 // softmax is a per-lane loop plus one cross-half exchange, and a lane stores its probabilities as 32 contiguous bytes.
-// Rounding contract (oracle/wan_dit.py `ctx_vo`): scores fp32 from bf16 q, k (+ fp32 key bias), p = 2^((s - max) * scale * log2 e) in fp32,
-// l = fp32 sum in key order per lane then across the two lane halves, P = bf16(p / l) (IEEE division).
+// Rounding contract (oracle/wan_dit.py `ctx_vo`): scores fp32 from bf16 q, k (+ fp32 key bias), p = 2^(t - max t), t = s * scale * log2 e
+// (* the query's RMS factor) + bias * log2 e, in fp32; l = fp32 sum in key order per lane then across the two lane halves,
+// P = bf16(p * (1 / l)) (one IEEE division per query).
+// q_row_sumsq: q arrives UN-normalised (the to_q projection's own bf16 output) together with the partial sums of squares of its rows that
+// the projection's epilogue emitted (v3a_gemm_args.row_sumsq); the per-row factor rsqrt(mean(q^2) + eps) of diffusers' RMSNorm across
+// heads multiplies the scores here, its per-column weight is folded into the cached keys by the host: the normalisation pass over q
+// (one launch, 50 MB of traffic per block and step) disappears.
 #include "common.h"
 #include "../../include/vist3a_hip.h"
 
@@ -25,7 +30,10 @@ struct XaP {
   long q_bs, k_bs, p_bs;   // elements per batch item
   int ldq, ldk, ldp;
   int H, Nq, Nk, Lkp, kbias_stride, kbias_first;
-  float scale_log2e, inv_scale;
+  float scale_log2e;
+  const float* qsq;        // optional [B * Nq][qparts]: partial sums of squares of the (un-normalised) q rows
+  int qparts;
+  float q_eps, inv_dim;
 };
 
 constexpr int D = 128, KV = 64, KROWB = D * 2, KTILE = KV * KROWB, NW = 4;
@@ -87,7 +95,18 @@ __global__ __launch_bounds__(256, 4) void xattn_probs_kernel(const XaP p) {
         s[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t][u], 0, 0, 0);
       }
     }
-  // ---- key bias (merged padding key), key-tail mask, maximum ----
+  // ---- the query's RMS factor (q not normalised yet): parts added in index order ----
+  float c = p.scale_log2e;
+  if (p.qsq) {
+    const float* sq = p.qsq + ((size_t)b * p.Nq + min(q0 + l31, p.Nq - 1)) * p.qparts;
+    float ss = 0.f;
+    for (int i = 0; i < p.qparts; i += 4) {
+      const f32x4 v = *(const f32x4*)(sq + i);
+      ss += v[0]; ss += v[1]; ss += v[2]; ss += v[3];
+    }
+    c *= rsqrtf(ss * p.inv_dim + p.q_eps);
+  }
+  // ---- t = s c + bias log2 e (merged padding key), key-tail mask, maximum ----
   float mx = -1e30f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -97,15 +116,14 @@ __global__ __launch_bounds__(256, 4) void xattn_probs_kernel(const XaP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = k0 + r;
-        float v = s[t][u][r];
-        if (p.kbias && key >= p.kbias_first && key < p.Nk) v += p.kbias[(size_t)b * p.kbias_stride + key] * p.inv_scale;
+        float v = s[t][u][r] * c;
+        if (p.kbias && key >= p.kbias_first && key < p.Nk) v += p.kbias[(size_t)b * p.kbias_stride + key] * 1.4426950408889634f;
         v = key < p.Nk ? v : -1e30f;
         s[t][u][r] = v;
         mx = fmaxf(mx, v);
       }
     }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  const float c = p.scale_log2e, mc = mx * c;
   float l = 0.f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -113,11 +131,12 @@ __global__ __launch_bounds__(256, 4) void xattn_probs_kernel(const XaP p) {
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][u][r], c, -mc));
+        const float e = __builtin_amdgcn_exp2f(s[t][u][r] - mx);
         s[t][u][r] = e;
         l += e;
       }
   l += __shfl_xor(l, 32, 64);
+  const float rl = 1.0f / l;
   // ---- P = bf16(p / l): 16 consecutive keys per lane and sub-tile = two 16-byte stores ----
   const int qr = q0 + l31;
   if (qr < p.Nq) {
@@ -131,8 +150,8 @@ __global__ __launch_bounds__(256, 4) void xattn_probs_kernel(const XaP p) {
           u32x4 w0, w1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            w0[e] = pack_bf16x2(s[t][u][2 * e] / l, s[t][u][2 * e + 1] / l);
-            w1[e] = pack_bf16x2(s[t][u][8 + 2 * e] / l, s[t][u][8 + 2 * e + 1] / l);
+            w0[e] = pack_bf16x2(s[t][u][2 * e] * rl, s[t][u][2 * e + 1] * rl);
+            w1[e] = pack_bf16x2(s[t][u][8 + 2 * e] * rl, s[t][u][8 + 2 * e + 1] * rl);
           }
           *(u32x4*)(prow + k0 * 2) = w0;
           *(u32x4*)(prow + k0 * 2 + 16) = w1;
@@ -156,7 +175,11 @@ extern "C" int v3a_xattn_probs_bf16(const v3a_xattn_probs_args* a, void* stream)
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldp = a->ldp;
   p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk; p.Lkp = a->Lkp;
   p.kbias_stride = a->key_bias_stride; p.kbias_first = a->key_bias_first > 0 ? a->key_bias_first : 0;
-  p.scale_log2e = a->scale * 1.4426950408889634f; p.inv_scale = 1.0f / a->scale;
+  p.scale_log2e = a->scale * 1.4426950408889634f;
+  if (a->q_row_sumsq) {
+    if (a->q_sumsq_parts <= 0 || a->q_sumsq_parts % 4) return V3A_ERR_SHAPE;
+    p.qsq = a->q_row_sumsq; p.qparts = a->q_sumsq_parts; p.q_eps = a->q_eps; p.inv_dim = 1.0f / (float)(a->H * 128);
+  }
   const int nt = a->Nk > 64 ? 2 : 1;
   const long wgs = (long)a->B * a->H * ((a->Nq + 127) / 128);
   if (wgs > 0x7fffffffL) return V3A_ERR_SHAPE;

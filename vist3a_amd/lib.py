@@ -34,7 +34,7 @@ class GemmArgs(C.Structure):
         ("out_row_group", C.c_int), ("out_row_skip", C.c_int), ("out_row_off", C.c_int),
         ("split_k", C.c_int), ("workspace", C.c_void_p),
         ("batch", C.c_int), ("a_batch_stride", C.c_long), ("b_batch_stride", C.c_long), ("c_batch_stride", C.c_long),
-        ("res_batch_stride", C.c_long),
+        ("res_batch_stride", C.c_long), ("row_sumsq", C.c_void_p),
     ]
 
 
@@ -122,6 +122,7 @@ class XattnProbsArgs(C.Structure):
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldp", C.c_int),
         ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("D", C.c_int), ("Lkp", C.c_int),
         ("key_bias_stride", C.c_int), ("key_bias_first", C.c_int), ("scale", C.c_float),
+        ("q_row_sumsq", C.c_void_p), ("q_sumsq_parts", C.c_int), ("q_eps", C.c_float),
     ]
 
 

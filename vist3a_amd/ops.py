@@ -88,10 +88,13 @@ def gemm(
     w_scale: Optional[torch.Tensor] = None,
     split_k: int = 1,
     batch: Optional[tuple] = None,
+    row_sumsq: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T); see v3a_gemm_bf16_nt for the epilogue order.
     batch = (count, a_stride, w_stride, out_stride[, residual_stride]) in elements: `count` problems of this shape in one launch, problem z
     offset by z * stride in each operand (0 = shared; residual_stride defaults to out_stride); a / w / out / residual describe problem 0.
+    row_sumsq (f32 [M, N // 32], written): per (row, 32-column block) sum of squares of bf16(acc + bias) - the statistics of an RMS norm the
+    consumer applies itself (ops.xattn_probs q_row_sumsq); plain bias epilogue only.
     out_rows=(group, skip, off) scatters output row m to m + (m//group)*skip + off (out must be given).
 
     scale: f32 [N] (LayerScale) or [nbatch, N] together with rows_per_batch (AdaLN gate).
@@ -110,7 +113,7 @@ def gemm(
         out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
     _chk2d(out, "out", (f32,) if out_f32 else (bf16,))
     # weight-streaming shapes (<= 128 rows against a big matrix) go to the skinny kernel: the tile GEMM would occupy N/128 CUs
-    plain = split_k <= 1 and batch is None and a_scale is None and scale is None and residual2 is None and out_rows is None and not relu_out and tile < 0 and res_row_mod == 0
+    plain = split_k <= 1 and batch is None and row_sumsq is None and a_scale is None and scale is None and residual2 is None and out_rows is None and not relu_out and tile < 0 and res_row_mod == 0
     if plain and K % 512 == 0 and K >= 1024:
         if M <= 128 and N >= 512 and not bias_row:
             return _gemm_skinny(a, w, bias, out, act, residual, out_f32, transposed=False)
@@ -150,6 +153,10 @@ def gemm(
         _ptr(residual2), residual2.stride(0) if residual2 is not None else 0, res_row_mod,
         *(out_rows if out_rows is not None else (0, 0, 0)),
     )
+    if row_sumsq is not None:
+        if a_scale is not None or row_sumsq.dtype != f32 or not row_sumsq.is_contiguous() or row_sumsq.numel() < M * (N // 32) or N % 32:
+            raise ValueError("row_sumsq must be contiguous f32 [M, N // 32] (bf16 GEMM, N % 32 == 0)")
+        args.row_sumsq = row_sumsq.data_ptr()
     nb = 1
     if batch is not None:
         if a_scale is not None or split_k > 1:
@@ -378,19 +385,25 @@ def attention(
 def xattn_probs(
     q: torch.Tensor, k: torch.Tensor, out: torch.Tensor, *, B: int, H: int, Nq: int, Nk: int, Lkp: int,
     q_batch_stride: int, k_batch_stride: int, p_batch_stride: int, scale: Optional[float] = None,
-    key_bias: Optional[torch.Tensor] = None, key_bias_first: int = 0,
+    key_bias: Optional[torch.Tensor] = None, key_bias_first: int = 0, q_row_sumsq: Optional[torch.Tensor] = None, q_eps: float = 1e-6,
 ) -> torch.Tensor:
     """Normalised cross-attention probabilities over <= 128 per-prompt keys (csrc/xattn_probs.hip, head_dim 128):
     out[b*p_batch_stride/ld + m, h*Lkp + j] = bf16(softmax_j(scale * q_h . k_h[j] + key_bias[b, j])), zeros for Nk <= j < Lkp.
-    q, k, out: 2-D bf16 views with row stride stride(0); key_bias fp32 [B, >= Nk] applies to keys >= key_bias_first."""
+    q, k, out: 2-D bf16 views with row stride stride(0); key_bias fp32 [B, >= Nk] applies to keys >= key_bias_first.
+    q_row_sumsq (f32 [B * Nq, parts], ops.gemm row_sumsq of the projection that made q): q is un-normalised; the scores of a query are
+    multiplied by rsqrt(sum(parts) / (H * 128) + q_eps), the row factor of the RMS norm across heads (fold its weight into k)."""
     for t, n in ((q, "q"), (k, "k"), (out, "out")):
         _chk2d(t, n, (bf16,))
     if key_bias is not None and (key_bias.dtype != f32 or key_bias.dim() != 2 or key_bias.shape[0] != B or key_bias.stride(1) != 1):
         raise ValueError("key_bias must be fp32 [B, n] with a contiguous last dim")
+    if q_row_sumsq is not None and (q_row_sumsq.dtype != f32 or q_row_sumsq.dim() != 2 or not q_row_sumsq.is_contiguous()
+                                    or q_row_sumsq.shape[0] < B * Nq or q_batch_stride != Nq * q.stride(0)):
+        raise ValueError("q_row_sumsq must be contiguous f32 [B * Nq, parts] over densely stacked batch items of q")
     args = L.XattnProbsArgs(
         _ptr(q), _ptr(k), _ptr(out), _ptr(key_bias), q_batch_stride, k_batch_stride, p_batch_stride,
         q.stride(0), k.stride(0), out.stride(0), B, H, Nq, Nk, 128, Lkp,
         key_bias.stride(0) if key_bias is not None else 0, key_bias_first, float(scale if scale is not None else 128 ** -0.5),
+        _ptr(q_row_sumsq), q_row_sumsq.shape[1] if q_row_sumsq is not None else 0, float(q_eps),
     )
     L.check(L.load().v3a_xattn_probs_bf16(C.byref(args), _stream()), "v3a_xattn_probs_bf16")
     return out

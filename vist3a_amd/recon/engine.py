@@ -119,13 +119,16 @@ class _DPT:
         self.nw, self.nb = Fv(p + "norm.weight"), Fv(p + "norm.bias")
         self.proj = [cw(f"projects.{i}") for i in range(4)]
         self.oc = [c.Cout for c in self.proj]
-        # ConvTranspose2d(k = stride): out[(y*k+dy),(x*k+dx),co] = sum_ci in[y,x,ci] W[ci,co,dy,dx] + b  ==  1x1 conv to k*k*co
+        # ConvTranspose2d(k = stride): out[(y*k+dy),(x*k+dx),co] = sum_ci in[y,x,ci] W[ci,co,dy,dx] + b  ==  for every dy a 1x1 conv to
+        # the k*co channels (dx, co) whose output row of pixel (y, x) is row y*k+dy of the upsampled image: the pixel shuffle is the
+        # GEMM epilogue's row scatter (out_rows), k launches writing the final layout instead of one launch plus a 109 MB permute copy
         self.up = []
         for i, k in ((0, 4), (1, 2)):
             w = sd[p + f"resize_layers.{i}.weight"]  # [ci, co, k, k]
             b = sd[p + f"resize_layers.{i}.bias"]
-            w1 = w.permute(2, 3, 1, 0).reshape(k * k * w.shape[1], w.shape[0], 1, 1)
-            self.up.append((ops.ConvWeight(w1, b.repeat(k * k), device=dev), k, w.shape[1]))
+            wk = w.permute(2, 3, 1, 0)               # [dy, dx, co, ci]
+            per_dy = [ops.ConvWeight(wk[dy].reshape(k * w.shape[1], w.shape[0], 1, 1), b.repeat(k), device=dev) for dy in range(k)]
+            self.up.append((per_dy, k, w.shape[1]))
         self.down = cw("resize_layers.3")
         s = "scratch."
         self.rn = [cw(s + f"layer{i + 1}_rn", bias=False) for i in range(4)]
@@ -300,9 +303,11 @@ class ReconEngine:
             n = ops.layernorm(tap, weight=hd.nw, bias=hd.nb, eps=1e-5, M=S * hw, in_rows=(hw, Pp - hw, nsp)).view(S, hp, wp, C2)
             x = ops.conv(n, hd.proj[i], residual=hd.pos(hd.proj[i].CoutP, hp, wp, W, H, dev), res_row_mod=hw)
             if i < 2:
-                cwt, k, co = hd.up[i]
-                y = ops.conv(x, cwt)  # [S,hp,wp,k*k*co]
-                x = y.view(S, hp, wp, k, k, co).permute(0, 1, 3, 2, 4, 5).reshape(S, hp * k, wp * k, co).contiguous()
+                per_dy, k, co = hd.up[i]
+                up = torch.empty(S, hp * k, wp, k * co, device=dev, dtype=bf16)   # = [S, hp*k, wp*k, co]
+                for dy, cwt in enumerate(per_dy):   # pixel m = (s, y, x) -> row ((s*hp + y)*k + dy)*wp + x of the [.., k*co] matrix
+                    ops.conv(x, cwt, out=up, out_rows=(wp, (k - 1) * wp, dy * wp))
+                x = up.view(S, hp * k, wp * k, co)
             elif i == 3:
                 x = ops.conv(x, hd.down, stride=(1, 2, 2), pad=(0, 1, 1))
             lv.append(ops.conv(x, hd.rn[i], pad=(0, 1, 1), relu_out=True))  # ReLU: only ever consumed through relu()

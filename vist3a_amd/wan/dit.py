@@ -100,7 +100,7 @@ class _Workspace:
         self.x = e(M, d)
         self.n = e(M, d)
         self.q2 = e(M, d)
-        self.p2 = None     # cross-attention probabilities [M, heads * padded keys] of the cached-context form, allocated on first use
+        self.p2 = self.q2sq = None   # cached-context cross-attention: probabilities [M, heads * padded keys] and the row statistics of q
         self.ao = e(M, d)
         self.h = e(M, cfg.ffn_dim)
         self.tok = e(M, cfg.in_channels * math.prod(cfg.patch_size))
@@ -235,9 +235,10 @@ class WanDiT:
         # identity of the tensor OBJECT (kept alive by the cache entry, so its address cannot be recycled for another prompt's
         # embeddings while the entry is live) + its in-place version counter
         ent = self._ctx.get(slot)
-        if ent is not None and ent[0][0] is text and ent[0][1] == text._version:
+        mode = (self.ctx_vo, self.gemm_dtype)   # the cached-context form stores keys with the query norm's weight folded in
+        if ent is not None and ent[0][0] is text and ent[0][1] == text._version and ent[0][2] == mode:
             return ent[1]
-        key = (text, text._version)
+        key = (text, text._version, mode)
         cfg = self.cfg
         d = cfg.dim
         Lp = (Lt + 63) // 64 * 64
@@ -246,10 +247,12 @@ class WanDiT:
             ks = [torch.empty(B * Lt, d, device=self.device, dtype=bf16) for _ in self.blocks]
             vts = [torch.zeros(d, B * Lp, device=self.device, dtype=bf16) for _ in self.blocks]
             kbias = torch.zeros(B, Lp, device=self.device, dtype=f32)
-            # [B, d, H * 128] per block: (V_h Wo_h^T) of the cached-context form, viewed [B, d, H * Lkp] for the prompt's key count
-            vwo_store = [torch.empty(B * d * H * 128, device=self.device, dtype=bf16) for _ in self.blocks] if (self.ctx_vo and hd == 128) else None
+            vwo_store = None
         else:
             ks, vts, kbias, vwo_store = ent[1][0], ent[1][1], ent[1][4], ent[1][9]
+        if vwo_store is None and self.ctx_vo and hd == 128 and self.gemm_dtype == "bf16":
+            # [B, d, H * 128] per block: (V_h Wo_h^T) of the cached-context form, viewed [B, d, H * Lkp] for the prompt's key count
+            vwo_store = [torch.empty(B * d * H * 128, device=self.device, dtype=bf16) for _ in self.blocks]
         # trailing all-zero rows (one host sync per prompt)
         nz = (text != 0).any(dim=-1)                                   # [B, Lt]
         last = torch.where(nz.any(dim=1), Lt - 1 - nz.flip(1).float().argmax(dim=1), torch.full((B,), -1, device=text.device))
@@ -275,16 +278,20 @@ class WanDiT:
         # one batched GEMM over the heads per (block, batch item); fp32 accumulation, rounded to bf16 once
         vwos, Lkp = None, 0
         gran = max(16, 64 // math.gcd(H, 64))    # keys per head padded so that the GEMM's K = H * Lkp is a multiple of 64 (16 at 12 / 40 heads)
-        if vwo_store is not None and (Lk + gran - 1) // gran * gran <= 128:
+        if vwo_store is not None and self.ctx_vo and self.gemm_dtype == "bf16" and (Lk + gran - 1) // gran * gran <= 128:
             Lkp = (Lk + gran - 1) // gran * gran
             Kp = H * Lkp
             vrow = torch.zeros(B * Lkp, d, device=self.device, dtype=bf16)
             vwos = [st[: B * d * Kp].view(B, d, Kp) for st in vwo_store]
-            for b, vwo in zip(self.blocks, vwos):
+            for b, vwo, k in zip(self.blocks, vwos, ks):
                 for bi in range(B):
                     vr = vrow[bi * Lkp: bi * Lkp + Lk]
                     ops.gemm(c[bi * Lt: bi * Lt + Lk], b["wv2"], b["bv2"], out=vr)
                     ops.gemm(b["wo2"][:, :hd], vrow[bi * Lkp:(bi + 1) * Lkp, :hd], out=vwo[bi][:, :Lkp], batch=(H, hd, hd, Lkp))
+                    # the query RMS norm's per-column weight moves onto the (already normalised) keys; its per-row factor is applied to
+                    # the scores by the probabilities kernel from the to_q projection's row statistics: q is never normalised in memory
+                    kr = k[bi * Lt: bi * Lt + Lk]
+                    kr.copy_((kr.float() * b["nq2"]).to(bf16))
         self._ctx[slot] = (key, (ks, vts, Lt, Lp, kbias, Lk, merged, vwos, Lkp, vwo_store))
         return self._ctx[slot][1]
 
@@ -454,18 +461,23 @@ class WanDiT:
             lin(ws.ao, b, "wo", b["bo"], out=x, residual=x, scale=m[:, 2], rows_per_batch=Nl)
             # --- cross attention
             norm(weight=b["n2w"], bias=b["n2b"])
-            lin(ws.n, b, "wq2", b["bq2"], out=ws.q2)
-            ops.rmsnorm_rope(ws.q2, b["nq2"], out=ws.q2, eps=cfg.eps)
             if vwos is not None and not g8:
-                # cached-context form: probabilities [B Nl, H Lkp], then ONE GEMM against the prompt's (V_h Wo_h^T), one B operand per batch item
+                # cached-context form: q stays the projection's raw output (its row statistics come out of the GEMM epilogue), the
+                # probabilities kernel applies the RMS factor and writes P [B Nl, H Lkp], then ONE GEMM against the prompt's
+                # (V_h Wo_h^T), one B operand per batch item
                 Kp = H * Lkp
                 if ws.p2 is None:
                     ws.p2 = torch.empty(Ml * H * 128, device=self.device, dtype=bf16)
+                    ws.q2sq = torch.empty(Ml, d // 32, device=self.device, dtype=f32)
                 p2 = ws.p2[: Ml * Kp].view(Ml, Kp)
+                ops.gemm(ws.n, b["wq2"], b["bq2"], out=ws.q2, row_sumsq=ws.q2sq)
                 ops.xattn_probs(ws.q2, ks[li], p2, B=B, H=H, Nq=Nl, Nk=Lk, Lkp=Lkp, q_batch_stride=Nl * d, k_batch_stride=Lt * d,
-                                p_batch_stride=Nl * Kp, key_bias=kbias if merged else None, key_bias_first=Lk - 1)
+                                p_batch_stride=Nl * Kp, key_bias=kbias if merged else None, key_bias_first=Lk - 1,
+                                q_row_sumsq=ws.q2sq, q_eps=cfg.eps)
                 ops.gemm(p2[:Nl], vwos[li][0], b["bo2"], out=x[:Nl], residual=x[:Nl], batch=(B, Nl * Kp, d * Kp, Nl * d))
             else:
+                lin(ws.n, b, "wq2", b["bq2"], out=ws.q2)
+                ops.rmsnorm_rope(ws.q2, b["nq2"], out=ws.q2, eps=cfg.eps)
                 ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lk, D=hd, q_batch_stride=Nl * d,
                               k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d, key_bias=kbias if merged else None,
                               key_bias_first=Lk - 1)

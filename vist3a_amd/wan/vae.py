@@ -125,7 +125,9 @@ class WanVAEDecoder:
             if mode is not None:
                 rs = cw(d + f"up_blocks.{i}.upsamplers.0.resample.1")
                 if mode == "upsample3d":
-                    tc = cw(d + f"up_blocks.{i}.upsamplers.0.time_conv")
+                    tw, tb = sd[d + f"up_blocks.{i}.upsamplers.0.time_conv.weight"], sd[d + f"up_blocks.{i}.upsamplers.0.time_conv.bias"]
+                    hc = tw.shape[0] // 2     # output channels [0, C) = odd frames, [C, 2C) = even frames of the doubled clip (decode_cl)
+                    tc = [ops.ConvWeight(tw[h * hc:(h + 1) * hc], tb[h * hc:(h + 1) * hc], device=dev) for h in range(2)]
             self.ups.append((res, mode, rs, tc, o_d))
         self.g_out = g(d + "norm_out.gamma")
         self.conv_out = cw(d + "conv_out")
@@ -164,11 +166,14 @@ class WanVAEDecoder:
                 continue
             T = x.shape[0]
             if mode == "upsample3d" and T > 1:
-                rest = ops.conv(x[1:].contiguous(), tc, pad=(2, 0, 0))  # [T-1,H,W,2C]
+                # time_conv emits 2C channels per frame t >= 1: the first C are frame 2t-1, the last C frame 2t of the doubled clip.  Two
+                # convolutions over the halves of the output channels write those frames in place (row scatter of the GEMM epilogue:
+                # pixel m of frame t-1 -> frame 1 + 2(t-1) + half) instead of one convolution plus two strided interleave copies.
+                HW = x.shape[1] * x.shape[2]
                 y = torch.empty((1 + 2 * (T - 1), *x.shape[1:]), device=x.device, dtype=bf16)
                 y[0] = x[0]
-                y[1::2] = rest[..., :C]
-                y[2::2] = rest[..., C:]
+                for half, tch in enumerate(tc):
+                    ops.conv(x[1:], tch, pad=(2, 0, 0), out=y, out_rows=(HW, HW, (1 + half) * HW))
                 x = y
             x = ops.conv(x, rs, pad=(0, 1, 1), ups2=True)
         n = ops.rownorm_act(x, self.g_out, mode=1, act=L.ACT_SILU)
