@@ -28,6 +28,9 @@ import torch
 from vist3a_amd.wan.dit import WAN_1_3B, WanDiT
 from vist3a_amd.wan.weights import random_dit_state_dict
 m = WanDiT(WAN_1_3B, random_dit_state_dict(WAN_1_3B, seed=0, device="cuda"))
+import os
+if os.environ.get("V3A_CTX_VO") == "0":
+    m.ctx_vo = False
 text = torch.zeros(2, 512, 4096, device="cuda")
 text[0, :64] = torch.randn(64, 4096, device="cuda") * 0.1
 text[1, :80] = torch.randn(80, 4096, device="cuda") * 0.1

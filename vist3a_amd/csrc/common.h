@@ -90,6 +90,33 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Sum of `parts` (% 4 == 0) consecutive floats in index order with the loads in flight TOGETHER: the partial sums of squares a GEMM epilogue
+// emitted for one row (v3a_gemm_args.row_sumsq).  A plain `for (i < parts)` loop waits for every 16-byte load in turn - a dozen serial L2
+// round trips in the prologue of every attention workgroup (measured: +18 us on the 185 us self-attention launch).
+__device__ __forceinline__ float sum_parts_in_order(const float* sq, int parts) {
+  float ss = 0.f;
+  int i = 0;
+  for (; i + 48 <= parts; i += 48) {   // 48 = 1536 / 32 (Wan-1.3B); 160 = 3 x 48 + 16 (Wan-14B)
+    f32x4 v[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) v[j] = *(const f32x4*)(sq + i + 4 * j);
+#pragma unroll
+    for (int j = 0; j < 12; ++j) { ss += v[j][0]; ss += v[j][1]; ss += v[j][2]; ss += v[j][3]; }
+  }
+  for (; i + 16 <= parts; i += 16) {
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *(const f32x4*)(sq + i + 4 * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ss += v[j][0]; ss += v[j][1]; ss += v[j][2]; ss += v[j][3]; }
+  }
+  for (; i < parts; i += 4) {
+    const f32x4 v = *(const f32x4*)(sq + i);
+    ss += v[0]; ss += v[1]; ss += v[2]; ss += v[3];
+  }
+  return ss;
+}
+
 // Bijective XCD-aware remap of a linear workgroup id: hardware places block b on XCD b%8;
 // give each XCD a contiguous chunk of the logical tile space so neighbouring tiles share its L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

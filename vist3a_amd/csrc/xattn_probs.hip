@@ -98,12 +98,7 @@ __global__ __launch_bounds__(256, 4) void xattn_probs_kernel(const XaP p) {
   // ---- the query's RMS factor (q not normalised yet): parts added in index order ----
   float c = p.scale_log2e;
   if (p.qsq) {
-    const float* sq = p.qsq + ((size_t)b * p.Nq + min(q0 + l31, p.Nq - 1)) * p.qparts;
-    float ss = 0.f;
-    for (int i = 0; i < p.qparts; i += 4) {
-      const f32x4 v = *(const f32x4*)(sq + i);
-      ss += v[0]; ss += v[1]; ss += v[2]; ss += v[3];
-    }
+    const float ss = sum_parts_in_order(p.qsq + ((size_t)b * p.Nq + min(q0 + l31, p.Nq - 1)) * p.qparts, p.qparts);
     c *= rsqrtf(ss * p.inv_dim + p.q_eps);
   }
   // ---- t = s c + bias log2 e (merged padding key), key-tail mask, maximum ----
