@@ -102,17 +102,29 @@ __global__ __launch_bounds__(256) void fuse_kernel(const FuseP p) {
       }
       dpart += mye;
       const int cnt = (int)min(16u, e - j0);
-      for (int i = 0; i < cnt; ++i) {
-        const size_t r = (size_t)__shfl(myr, gbase + i, 64);
-        const float w = __shfl(mye, gbase + i, 64);
-        const float* row = p.feat + r * ldf;
-        float v[NK];
+      // four points per trip: their rows are requested together (4 x NK loads in flight instead of NK - a crowded voxel, e.g. the
+      // collapsed cloud of seeded random weights with ~76 points per voxel, is a serial chain of row fetches otherwise: 4.3 ms per scene),
+      // the FMAs then run in the same ascending point order as before
+      for (int i = 0; i < cnt; i += 4) {
+        float v[4][NK], pv[4], w[4];
 #pragma unroll
-        for (int k = 0; k < NK; ++k) v[k] = (sl + 16 * k < p.nfeat) ? row[sl + 16 * k] : 0.f;
-        const float pv = sl < 3 ? p.pts[r * 3 + sl] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+          const int src = gbase + min(i + q, 15);
+          const size_t r = (size_t)__shfl(myr, src, 64);
+          w[q] = __shfl(mye, src, 64);
+          const float* row = p.feat + r * ldf;
 #pragma unroll
-        for (int k = 0; k < NK; ++k) acc[k] = fmaf(v[k], w, acc[k]);
-        ap = fmaf(pv, w, ap);
+          for (int k = 0; k < NK; ++k) v[q][k] = (i + q < cnt && sl + 16 * k < p.nfeat) ? row[sl + 16 * k] : 0.f;
+          pv[q] = (i + q < cnt && sl < 3) ? p.pts[r * 3 + sl] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (i + q < cnt) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) acc[k] = fmaf(v[q][k], w[q], acc[k]);
+            ap = fmaf(pv[q], w[q], ap);
+          }
+        }
       }
     }
 #pragma unroll
