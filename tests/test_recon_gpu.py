@@ -246,3 +246,38 @@ def test_boundary_conf_valid_mask_matches_reference_golden(hip_lib):
     m.encoder.cfg.render_conf = False
     out_n = m(g["latent"].cuda(), g["image"].cuda(), train=False)
     assert bool(out_n.depth_dict["conf_valid_mask"].all()) and out_n.depth_dict["conf_valid_mask"].shape == ref_mask.shape
+
+
+def test_batched_forward_assembles_scenes_like_the_reference(hip_lib):
+    """AnySplatStitched.forward with b = 2 (anysplat_stitched.py:174-202, 417-453): every scene's slice equals its own b = 1 forward bit
+    for bit; the scene with fewer voxels is padded to the larger count with rows whose opacity is exactly 0 (features -1e10 -> density
+    sigmoid(-1e10) = 0, points -1e4); poses / depth carry the batch dimension; scene_scale is the mean point norm over the whole batch."""
+    from safetensors.torch import load_file
+    from pathlib import Path
+    from vist3a_amd.models.anysplat_stitched import AnySplatStitched, AnySplatWeights
+    from vist3a_amd.recon.engine import ReconCfg
+    g = load_file(str(Path(__file__).parent / "golden" / "recon_tiny_conf.safetensors"))
+    kw = dict(C=64, heads=1, n_dino=22, depth=24, cam_heads=2, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+    sd = R.make_recon_weights(R.ReconCfg(**kw), seed=41)
+    m = AnySplatStitched(AnySplatWeights(dict(sd), ReconCfg(**kw, voxelize=True, voxel_size=0.05)), "enc_blocks_2", "cuda")
+    lat, img = g["latent"].cuda(), g["image"].cuda()
+    gen = torch.Generator().manual_seed(5)
+    lat2 = torch.cat([lat, lat + 0.3 * torch.randn(lat.shape, generator=gen).cuda()], 0)
+    img2 = torch.cat([img, (img * 0.7).clamp(-1, 1)], 0)
+    singles = []
+    for b in range(2):
+        o = m(lat2[b:b + 1], img2[b:b + 1], train=False)
+        singles.append({k: getattr(o.gaussians, k).clone() for k in ("means", "covariances", "harmonics", "opacities", "scales", "rotations")}
+                       | dict(pose=o.pred_pose_enc_list[-1].clone(), depth=o.depth_dict["depth"].clone(), ext=o.pred_context_pose["extrinsic"].clone(),
+                              scale=o.infos["scene_scale"].clone()))
+    out, anchor, conf, dconf = m(lat2, img2, train=True)
+    U = [s["means"].shape[1] for s in singles]
+    assert out.gaussians.means.shape[:2] == (2, max(U)) and U[0] != U[1]
+    for b in range(2):
+        for k in ("means", "covariances", "harmonics", "opacities", "scales", "rotations"):
+            assert torch.equal(getattr(out.gaussians, k)[b, :U[b]], singles[b][k][0]), (b, k)
+        assert bool((out.gaussians.opacities[b, U[b]:] == 0).all())
+        assert torch.equal(out.pred_pose_enc_list[-1][b], singles[b]["pose"][0]) and torch.equal(out.depth_dict["depth"][b], singles[b]["depth"][0])
+        assert torch.allclose(out.pred_context_pose["extrinsic"][b], singles[b]["ext"][0], atol=1e-6, rtol=1e-6)   # (batched 4x4 inverse)
+    assert anchor.shape[:2] == (2, img.shape[2]) and conf.shape == dconf.shape == out.depth_dict["conf_valid_mask"].shape
+    assert abs(out.infos["scene_scale"].item() - 0.5 * (singles[0]["scale"].item() + singles[1]["scale"].item())) < 1e-5 * out.infos["scene_scale"].item()

@@ -247,14 +247,17 @@ struct LinP {
   const float* x; const float* w; const float* b; float* y; const float* res; const float* gamma;
   int M, N, K, ldx, ldy, ldr, act;
 };
-// One wave per NPW consecutive outputs: every x fragment fetched from L1/L2 is used against NPW weight rows (with one output
-// per wave the 13 activation loads per 16-byte weight load, not the weight stream, set the pace: 0.7 TB/s).  Per output the k-order of
-// the partial sums is unchanged.
-template <int MAXM, int NPW>
+// One wave per NPW consecutive outputs: every x fragment is used against NPW weight rows (with one output per wave the 13 activation
+// loads per 16-byte weight load, not the weight stream, set the pace: 0.7 TB/s).  Per output the k-order of the partial sums is unchanged.
+// Round 4: the activations of a K chunk (M rows x KC floats, <= 52 KB) are staged ONCE per workgroup in LDS and read from there by its four
+// waves.  Before, every wave re-read all of x (13 x 8 KB at the camera trunk's K = 2048) through L1 / L2 - 3072 waves x 106 KB = 326 MB of
+// L2 traffic beside the 50 MB qkv weight: the kernel ran at 0.9 TB/s of weight stream.  Same arithmetic, same summation order.
+template <int MAXM, int NPW, int KC>
 __global__ __launch_bounds__(256) void linear_f32_kernel(const LinP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sx = (float*)smem;                                   // [M][KC]
   const int lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW;
-  if (n0 >= p.N) return;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW;   // (a wave past N still takes part in the staging and the barriers)
   float acc[NPW][MAXM];
 #pragma unroll
   for (int j = 0; j < NPW; ++j)
@@ -263,16 +266,25 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const LinP p) {
   const float* wr[NPW];
 #pragma unroll
   for (int j = 0; j < NPW; ++j) wr[j] = p.w + (size_t)min(n0 + j, p.N - 1) * p.K;   // (rows past N are computed and dropped)
-  for (int k = lane * 4; k < p.K; k += 256) {
-    f32x4 wv[NPW];
+  for (int k0 = 0; k0 < p.K; k0 += KC) {
+    const int kc = min(KC, p.K - k0);                          // K % 4 == 0
+    if (k0) __syncthreads();
+    for (int i = threadIdx.x * 4; i < p.M * kc; i += 1024) {
+      const int m = i / kc, kk = i - m * kc;
+      *(f32x4*)(sx + m * KC + kk) = *(const f32x4*)(p.x + (size_t)m * p.ldx + k0 + kk);
+    }
+    __syncthreads();
+    for (int kk = lane * 4; kk < kc; kk += 256) {
+      f32x4 wv[NPW];
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) wv[j] = *(const f32x4*)(wr[j] + k);
+      for (int j = 0; j < NPW; ++j) wv[j] = *(const f32x4*)(wr[j] + k0 + kk);
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      if (m < p.M) {
-        const f32x4 xv = *(const f32x4*)(p.x + (size_t)m * p.ldx + k);
+      for (int m = 0; m < MAXM; ++m) {
+        if (m < p.M) {
+          const f32x4 xv = *(const f32x4*)(sx + m * KC + kk);
 #pragma unroll
-        for (int j = 0; j < NPW; ++j) acc[j][m] += wv[j][0] * xv[0] + wv[j][1] * xv[1] + wv[j][2] * xv[2] + wv[j][3] * xv[3];
+          for (int j = 0; j < NPW; ++j) acc[j][m] += wv[j][0] * xv[0] + wv[j][1] * xv[1] + wv[j][2] * xv[2] + wv[j][3] * xv[3];
+        }
       }
     }
   }
@@ -394,8 +406,9 @@ extern "C" int v3a_linear_f32(const float* x, const float* w, const float* bias,
   if (!x || !w || !y) return V3A_ERR_ARG;
   if (M <= 0 || M > 32 || N <= 0 || K <= 0 || K % 4 || ldx % 4) return V3A_ERR_SHAPE;
   LinP p{x, w, bias, y, residual, gamma, M, N, K, ldx, ldy, ldr, act};
-  if (M <= 16) hipLaunchKernelGGL((linear_f32_kernel<16, 4>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((linear_f32_kernel<32, 2>), dim3((N + 7) / 8), dim3(256), 0, (hipStream_t)stream, p);
+  // LDS: M rows x KC floats of x per workgroup (16 x 1024 x 4 B = 64 KB, 32 x 512 x 4 B = 64 KB)
+  if (M <= 16) hipLaunchKernelGGL((linear_f32_kernel<16, 4, 1024>), dim3((N + 15) / 16), dim3(256), (size_t)M * 1024 * 4, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((linear_f32_kernel<32, 2, 512>), dim3((N + 7) / 8), dim3(256), (size_t)M * 512 * 4, (hipStream_t)stream, p);
   return LAUNCH_OK();
 }
 

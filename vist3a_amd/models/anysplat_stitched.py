@@ -120,7 +120,54 @@ class AnySplatStitched(torch.nn.Module):
     @torch.no_grad()
     def forward(self, context_latent: torch.Tensor, context_image: torch.Tensor, train: bool = False):
         B, c, S, H, W = context_image.shape
-        if B != 1 or context_latent.shape[0] != 1:
-            raise NotImplementedError("batch size 1 (the reference's inference path decodes one scene at a time)")
-        out = self.engine().forward(context_latent, context_image)
-        return self.package(out, S, H, W, train)
+        if context_latent.shape[0] != B:
+            raise ValueError("context_latent and context_image disagree on the batch size")
+        if B == 1:
+            out = self.engine().forward(context_latent, context_image)
+            return self.package(out, S, H, W, train)
+        return self._forward_batched(context_latent, context_image, train)
+
+    def _forward_batched(self, context_latent: torch.Tensor, context_image: torch.Tensor, train: bool):
+        """b > 1 (anysplat_stitched.py:174-202 folds (b v) into the token batch; every scene is still reconstructed on its own views): one
+        engine forward per scene, then the reference's batch assembly - per-scene voxel lists padded to the largest count with features
+        -1e10 / points -1e4 (:440-453: a padded row has density sigmoid(-1e10) = 0, i.e. opacity 0), the Gaussian adapter over the padded
+        rows, `scene_scale` taken over the whole batch (:411-412).  The reference takes the `render_conf` quantile over the whole batch as
+        well (:381-387); that branch is not assembled here."""
+        from .. import ops
+        eng = self.engine()
+        if eng.cfg.render_conf:
+            raise NotImplementedError("render_conf with batch > 1: the reference's confidence quantile spans the batch")
+        B, _, S, H, W = context_image.shape
+        outs = []
+        for b in range(B):
+            o = eng.forward(context_latent[b:b + 1], context_image[b:b + 1])
+            keep = ("pred_pose_enc_list", "depth", "depth_conf", "pts_all", "raw_gs", "extrinsic_w2c", "intrinsic_px", "neural_pts", "neural_feats")
+            outs.append({k: ([t.clone() for t in o[k]] if isinstance(o[k], list) else o[k].clone()) for k in keep})   # the engine reuses its buffers
+        U = max(o["neural_feats"].shape[0] for o in outs)
+        dev = outs[0]["neural_feats"].device
+        gs = []
+        for o in outs:
+            n, nf = o["neural_feats"].shape
+            feats = torch.full((U, nf), -1e10, device=dev, dtype=torch.float32)
+            pts = torch.full((U, 3), -1e4, device=dev, dtype=torch.float32)
+            feats[:n], pts[:n] = o["neural_feats"], o["neural_pts"]
+            gs.append(ops.gaussian_adapter(pts, feats, eng.sh_mask, eng.cfg.sh_degree, eng.cfg.opacity_exponent))
+        gauss = Gaussians(**{k: torch.stack([g[k] for g in gs], 0) for k in gs[0]})
+        ext = torch.stack([o["extrinsic_w2c"] for o in outs], 0)
+        K = torch.stack([o["intrinsic_px"] for o in outs], 0)
+        pad = torch.tensor([0, 0, 0, 1.0], device=dev, dtype=ext.dtype).view(1, 1, 1, 4).repeat(B, S, 1, 1)
+        Kn = torch.stack([K[:, :, 0] / W, K[:, :, 1] / H, K[:, :, 2]], 2)
+        pose = dict(extrinsic=torch.cat([ext, pad], 2).inverse(), intrinsic=Kn)
+        depth = torch.stack([o["depth"] for o in outs], 0).view(B, S, H, W, 1)
+        dconf = torch.stack([o["depth_conf"] for o in outs], 0).view(B, S, H, W)
+        poses = [torch.stack([o["pred_pose_enc_list"][i] for o in outs], 0) for i in range(len(outs[0]["pred_pose_enc_list"]))]
+        scale = torch.stack([o["pts_all"].reshape(-1, 3) for o in outs], 0).norm(dim=-1).mean().clip(min=1e-8)
+        eo = EncoderOutput(gaussians=gauss, pred_pose_enc_list=poses, pred_context_pose=pose,
+                           depth_dict=dict(depth=depth, conf_valid_mask=torch.ones_like(dconf, dtype=torch.bool)),
+                           infos=dict(scene_scale=scale, voxelize_ratio=U / (H * W * S)), distill_infos=None,
+                           last_pred_pose_enc=None if train else poses[-1])
+        if not train:
+            return eo
+        gsd = self.encoder.raw_gs_dim
+        raw = torch.stack([o["raw_gs"] for o in outs], 0).view(B, S, H, W, -1).permute(0, 1, 4, 2, 3)
+        return eo, raw[:, :, :gsd], raw[:, :, gsd], dconf

@@ -378,6 +378,7 @@ class ReconEngine:
             vp, vf = c["pts"], c["feat"]
         else:
             vp, vf = pts.view(M, 3), raw_gs[:, :gsd]
+        out["neural_pts"], out["neural_feats"] = vp, vf      # per-point / per-voxel inputs of the adapter (batched forwards pad and re-run it)
         out["gaussians"] = ops.gaussian_adapter(vp, vf, self.sh_mask, cfg.sh_degree, cfg.opacity_exponent)
         out["scene_scale"] = pts.view(-1, 3).norm(dim=-1).mean().clip(min=1e-8)
         out["num_points"] = M
