@@ -246,6 +246,11 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
             f"{p} not found: build it with `python -m vist3a_amd.build` (hipcc, gfx950). "
             "The VIST3A MI355X path has no fallback implementation."
         )
+    # The library links against libamdhip64; PyTorch-ROCm ships its own copy.  Whichever is mapped FIRST becomes the process's HIP runtime
+    # for that soname: if this .so came first, its kernels would be registered with /opt/rocm's runtime while every stream and device
+    # pointer it is handed belongs to torch's - the first launch then fails with V3A_ERR_LAUNCH (seen when build() and smoke() ran in one
+    # process).  Import torch first so that there is exactly one runtime.
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(str(p))
     except OSError as e:  # pragma: no cover - depends on the ROCm runtime being present
