@@ -227,3 +227,40 @@ def test_loaders_apply_every_checkpoint_piece(hip_lib, tmp_path):
     ed, ed0 = rel(y, ref), rel(y, ref0)
     print(f"loader: DiT vs oracle with the adapter {ed:.2e}, without {ed0:.2e}")
     assert ed < 6e-3 and ed0 > 3 * ed
+
+
+def test_bench_emits_the_contract_line(hip_lib):
+    """`bench.py` end to end on a shortened schedule (2 denoise steps, one scene, no CPU baseline leg): exactly one JSON line on stdout with
+    the driver's fields, the BASELINE metric / workload, the `roofline` object of the dominant kernel with a live-measured fraction, and a
+    value consistent with ms_per_step."""
+    import json, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "1", "--warmup", "0", "--denoise-steps", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["unit"] == "scenes/s" and j["n_gpus"] == 1 and j["steps"] == 1 and j["warmup"] == 0 and j["higher_is_better"] is True
+    assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "bf16" and "synthetic" in j["data"]
+    assert "Wan-1.3B" in j["config"]["workload"] and j["config"]["views"] == 13 and j["config"]["denoise_steps"] == 2 and "model" not in j["config"]
+    assert abs(j["value"] * j["ms_per_step"] / 1e3 - 1.0) < 1e-6
+    rf = j["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and 0.2 < rf["frac"] < 0.8 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    assert "cpu_baseline" not in j      # (--no-cpu-baseline; the default run adds the object: profiles/rNN/bench_default_run.json)
+
+
+def test_graft_entry_build_then_smoke_in_one_process(hip_lib):
+    """`python __graft_entry__.py smoke` = build() followed by smoke() in ONE process: the library must come up on torch's HIP runtime even
+    though build() maps it before anything touches the GPU (lib.load imports torch first; with the system runtime mapped first the first
+    launch failed with V3A_ERR_LAUNCH)."""
+    import subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "__graft_entry__.py"), "smoke"], capture_output=True, text=True, timeout=900, cwd=str(root))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "[smoke] DiT rel err vs oracle" in r.stdout and "voxel keys bit-exact" in r.stdout
