@@ -196,6 +196,11 @@ class WanDiT:
         self.tx2_w, self.tx2_b = W(ce + "text_embedder.linear_2.weight"), Fv(ce + "text_embedder.linear_2.bias")
         self.blocks = []
         tables = []
+        # cross-attention K | V projections of ALL blocks stacked [L, 2, d, d] (k rows then v rows per block): the per-prompt context is one
+        # weight-streaming GEMM per batch item over the stack instead of two tiny launches per block; b["wk2"] / b["wv2"] are views of it
+        nl = cfg.num_layers
+        self.ctx_w = torch.empty(nl, 2, d, d, device=dev, dtype=bf16)
+        self.ctx_b = torch.empty(nl, 2, d, device=dev, dtype=f32)
         for i in range(cfg.num_layers):
             p = f"blocks.{i}."
             b = {}
@@ -206,14 +211,16 @@ class WanDiT:
             b["nq"], b["nk"] = Fv(p + "attn1.norm_q.weight"), Fv(p + "attn1.norm_k.weight")
             b["n2w"], b["n2b"] = Fv(p + "norm2.weight"), Fv(p + "norm2.bias")
             b["wq2"], b["bq2"] = W(p + "attn2.to_q.weight"), Fv(p + "attn2.to_q.bias")
-            b["wk2"], b["bk2"] = W(p + "attn2.to_k.weight"), Fv(p + "attn2.to_k.bias")
-            b["wv2"], b["bv2"] = W(p + "attn2.to_v.weight"), Fv(p + "attn2.to_v.bias")
+            self.ctx_w[i, 0].copy_(sd[p + "attn2.to_k.weight"]); self.ctx_b[i, 0].copy_(sd[p + "attn2.to_k.bias"])
+            self.ctx_w[i, 1].copy_(sd[p + "attn2.to_v.weight"]); self.ctx_b[i, 1].copy_(sd[p + "attn2.to_v.bias"])
+            b["wk2"], b["bk2"], b["wv2"], b["bv2"] = self.ctx_w[i, 0], self.ctx_b[i, 0], self.ctx_w[i, 1], self.ctx_b[i, 1]
             b["wo2"], b["bo2"] = W(p + "attn2.to_out.0.weight"), Fv(p + "attn2.to_out.0.bias")
             b["nq2"], b["nk2"] = Fv(p + "attn2.norm_q.weight"), Fv(p + "attn2.norm_k.weight")
             b["w1"], b["b1"] = W(p + "ffn.net.0.proj.weight"), Fv(p + "ffn.net.0.proj.bias")
             b["w2"], b["b2"] = W(p + "ffn.net.2.weight"), Fv(p + "ffn.net.2.bias")
             tables.append(sd[p + "scale_shift_table"].to(device=dev, dtype=f32).reshape(6, d))
             self.blocks.append(b)
+        self.nq2_all = torch.stack([b["nq2"] for b in self.blocks], 0).contiguous()   # [L, d]: folded into the cached keys (ctx_vo)
         self.sst = torch.stack(tables, 0).contiguous()  # [L,6,d]
         self.out_sst = sd["scale_shift_table"].to(device=dev, dtype=f32).reshape(2, d).contiguous()
         self.po_w, self.po_b = W("proj_out.weight"), Fv("proj_out.bias")
@@ -243,13 +250,17 @@ class WanDiT:
         d = cfg.dim
         Lp = (Lt + 63) // 64 * 64
         H, hd = cfg.num_attention_heads, cfg.attention_head_dim
+        nl = len(self.blocks)
         if ent is None:
-            ks = [torch.empty(B * Lt, d, device=self.device, dtype=bf16) for _ in self.blocks]
+            # K | V rows of every block in ONE buffer [B * Lt, L * 2d] (row = context token, columns = (block, k | v, channel)): what
+            # the stacked projection writes; ks[l] is the strided [B * Lt, d] view of block l's keys
+            kv = torch.zeros(B * Lt, nl * 2 * d, device=self.device, dtype=bf16)
+            ks = [kv[:, 2 * d * l: 2 * d * l + d] for l in range(nl)]
             vts = [torch.zeros(d, B * Lp, device=self.device, dtype=bf16) for _ in self.blocks]
             kbias = torch.zeros(B, Lp, device=self.device, dtype=f32)
             vwo_store = None
         else:
-            ks, vts, kbias, vwo_store = ent[1][0], ent[1][1], ent[1][4], ent[1][9]
+            ks, vts, kbias, vwo_store, kv = ent[1][0], ent[1][1], ent[1][4], ent[1][9], ent[1][10]
         if vwo_store is None and self.ctx_vo and hd == 128 and self.gemm_dtype == "bf16":
             # [B, d, H * 128] per block: (V_h Wo_h^T) of the cached-context form, viewed [B, d, H * Lkp] for the prompt's key count
             vwo_store = [torch.empty(B * d * H * 128, device=self.device, dtype=bf16) for _ in self.blocks]
@@ -267,32 +278,40 @@ class WanDiT:
         t2 = text.reshape(B * Lt, -1).to(bf16).contiguous()
         c = ops.gemm(t2, self.tx1_w, self.tx1_b, act=L.ACT_GELU_TANH)
         c = ops.gemm(c, self.tx2_w, self.tx2_b)
-        for b, k, vt in zip(self.blocks, ks, vts):
-            for bi in range(B):  # the first Lk rows of every batch item (merged: row Lk-1 represents all padding rows from there on)
-                rows = slice(bi * Lt, bi * Lt + Lk)
-                ops.gemm(c[rows], b["wk2"], b["bk2"], out=k[rows])
-                ops.rmsnorm_rope(k[rows], b["nk2"], out=k[rows], eps=cfg.eps)
-                # V^T per batch item so each lands at its 64-padded column block
-                ops.gemm(b["wv2"], c[rows], b["bv2"], out=vt[:, bi * Lp: bi * Lp + Lk], bias_row=True)
-        # cached-context cross-attention: V rows [Lkp, d] (zero past Lk) -> VWo[b][n, h * Lkp + j] = sum_c Wo[n, h hd + c] V[j, h hd + c],
-        # one batched GEMM over the heads per (block, batch item); fp32 accumulation, rounded to bf16 once
-        vwos, Lkp = None, 0
         gran = max(16, 64 // math.gcd(H, 64))    # keys per head padded so that the GEMM's K = H * Lkp is a multiple of 64 (16 at 12 / 40 heads)
-        if vwo_store is not None and self.ctx_vo and self.gemm_dtype == "bf16" and (Lk + gran - 1) // gran * gran <= 128:
-            Lkp = (Lk + gran - 1) // gran * gran
+        Lkp = (Lk + gran - 1) // gran * gran
+        use_vo = vwo_store is not None and self.ctx_vo and self.gemm_dtype == "bf16" and Lkp <= min(128, Lt)
+        # K and V rows of ALL blocks for the first Lk rows of every batch item (merged: row Lk-1 represents all padding rows from there on):
+        # one weight-streaming launch per batch item over the stacked [L * 2d, d] projection (120 two-launch skinny GEMMs before: 4 ms per prompt)
+        wall, ball = self.ctx_w.view(nl * 2 * d, d), self.ctx_b.view(-1)
+        for bi in range(B):
+            ops.gemm(c[bi * Lt: bi * Lt + Lk], wall, ball, out=kv[bi * Lt: bi * Lt + Lk])
+            if use_vo and Lkp > Lk:
+                kv[bi * Lt + Lk: bi * Lt + Lkp].zero_()        # the padded key rows of V feed the V.Wo^T GEMM (their probabilities are exactly 0)
+        for li, (b, k) in enumerate(zip(self.blocks, ks)):
+            for bi in range(B):
+                rows = slice(bi * Lt, bi * Lt + Lk)
+                ops.rmsnorm_rope(k[rows], b["nk2"], out=k[rows], eps=cfg.eps)
+        # cached-context cross-attention: VWo[b][n, h * Lkp + j] = sum_c Wo[n, h hd + c] V[j, h hd + c], one batched GEMM over the heads per
+        # (block, batch item) straight from the V rows of the projection buffer; fp32 accumulation, rounded to bf16 once
+        vwos = None
+        if use_vo:
             Kp = H * Lkp
-            vrow = torch.zeros(B * Lkp, d, device=self.device, dtype=bf16)
             vwos = [st[: B * d * Kp].view(B, d, Kp) for st in vwo_store]
-            for b, vwo, k in zip(self.blocks, vwos, ks):
+            for li, (b, vwo) in enumerate(zip(self.blocks, vwos)):
                 for bi in range(B):
-                    vr = vrow[bi * Lkp: bi * Lkp + Lk]
-                    ops.gemm(c[bi * Lt: bi * Lt + Lk], b["wv2"], b["bv2"], out=vr)
-                    ops.gemm(b["wo2"][:, :hd], vrow[bi * Lkp:(bi + 1) * Lkp, :hd], out=vwo[bi][:, :Lkp], batch=(H, hd, hd, Lkp))
-                    # the query RMS norm's per-column weight moves onto the (already normalised) keys; its per-row factor is applied to
-                    # the scores by the probabilities kernel from the to_q projection's row statistics: q is never normalised in memory
-                    kr = k[bi * Lt: bi * Lt + Lk]
-                    kr.copy_((kr.float() * b["nq2"]).to(bf16))
-        self._ctx[slot] = (key, (ks, vts, Lt, Lp, kbias, Lk, merged, vwos, Lkp, vwo_store))
+                    vrows = kv[bi * Lt: bi * Lt + Lkp, 2 * d * li + d: 2 * d * li + d + hd]     # [Lkp, hd] of head 0; heads hd columns apart
+                    ops.gemm(b["wo2"][:, :hd], vrows, out=vwo[bi][:, :Lkp], batch=(H, hd, hd, Lkp))
+            # the query RMS norm's per-column weight moves onto the (already normalised) keys, all blocks at once; its per-row factor is
+            # applied to the scores by the probabilities kernel from the to_q projection's row statistics: q is never normalised in memory
+            k5 = kv.view(B, Lt, nl, 2, d)[:, :Lk, :, 0]
+            k5.copy_((k5.float() * self.nq2_all).to(bf16))
+        else:
+            Lkp = 0
+            for li, (b, vt) in enumerate(zip(self.blocks, vts)):   # flash form: V^T per batch item, each at its 64-padded column block
+                for bi in range(B):
+                    ops.gemm(b["wv2"], c[bi * Lt: bi * Lt + Lk], b["bv2"], out=vt[:, bi * Lp: bi * Lp + Lk], bias_row=True)
+        self._ctx[slot] = (key, (ks, vts, Lt, Lp, kbias, Lk, merged, vwos, Lkp, vwo_store, kv))
         return self._ctx[slot][1]
 
     # ---------------------------------------------------------------- forward
@@ -322,7 +341,8 @@ class WanDiT:
         if rope is None:
             rope = self._rope[(ppf, pph, ppw)] = rope_table(cfg, ppf, pph, ppw, self.device)
         rope = rope[rk * Nl:(rk + 1) * Nl]
-        ks, vts, Lt, Lp, kbias, Lk, merged, vwos, Lkp, _ = self._context(encoder_hidden_states)
+        ks, vts, Lt, Lp, kbias, Lk, merged, vwos, Lkp = self._context(encoder_hidden_states)[:9]
+        kbs = Lt * ks[0].stride(0)      # keys of a batch item: Lt rows of the stacked projection buffer
 
         # patchify: Conv3d(k=s=(1,2,2)) == GEMM over (c,pt,ph,pw)-major patches
         if not tokens_in:
@@ -471,7 +491,7 @@ class WanDiT:
                     ws.q2sq = torch.empty(Ml, d // 32, device=self.device, dtype=f32)
                 p2 = ws.p2[: Ml * Kp].view(Ml, Kp)
                 ops.gemm(ws.n, b["wq2"], b["bq2"], out=ws.q2, row_sumsq=ws.q2sq)
-                ops.xattn_probs(ws.q2, ks[li], p2, B=B, H=H, Nq=Nl, Nk=Lk, Lkp=Lkp, q_batch_stride=Nl * d, k_batch_stride=Lt * d,
+                ops.xattn_probs(ws.q2, ks[li], p2, B=B, H=H, Nq=Nl, Nk=Lk, Lkp=Lkp, q_batch_stride=Nl * d, k_batch_stride=kbs,
                                 p_batch_stride=Nl * Kp, key_bias=kbias if merged else None, key_bias_first=Lk - 1,
                                 q_row_sumsq=ws.q2sq, q_eps=cfg.eps)
                 ops.gemm(p2[:Nl], vwos[li][0], b["bo2"], out=x[:Nl], residual=x[:Nl], batch=(B, Nl * Kp, d * Kp, Nl * d))
@@ -479,7 +499,7 @@ class WanDiT:
                 lin(ws.n, b, "wq2", b["bq2"], out=ws.q2)
                 ops.rmsnorm_rope(ws.q2, b["nq2"], out=ws.q2, eps=cfg.eps)
                 ops.attention(ws.q2, ks[li], vts[li], ws.ao, B=B, H=H, Nq=Nl, Nk=Lk, D=hd, q_batch_stride=Nl * d,
-                              k_batch_stride=Lt * d, vt_batch_stride=Lp, o_batch_stride=Nl * d, key_bias=kbias if merged else None,
+                              k_batch_stride=kbs, vt_batch_stride=Lp, o_batch_stride=Nl * d, key_bias=kbias if merged else None,
                               key_bias_first=Lk - 1)
                 lin.last = None
                 lin(ws.ao, b, "wo2", b["bo2"], out=x, residual=x)
