@@ -24,6 +24,14 @@ if len(sys.argv) > 2 and sys.argv[1] == "--report":
     print(json.dumps(dict(kernels=len(sel), busy_ms=round(busy / 1e3, 2), span_ms=round((sel[-1][1] - sel[0][0]) / 1e6, 2),
                           glue_launches=sum(len(v) for v in glue.values()), glue_ms=round(sum(sum(v) for v in glue.values()) / 1e3, 3),
                           glue_share_pct=round(100 * sum(sum(v) for v in glue.values()) / busy, 3))))
+    # where the GPU idles: gaps > 20 us between consecutive kernels, by the kernel that follows them
+    gaps = collections.defaultdict(lambda: [0, 0.0])
+    for a, b in zip(sel[:-1], sel[1:]):
+        g = (b[0] - a[1]) / 1e3
+        if g > 20:
+            k = b[2].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:60]
+            gaps[k][0] += 1; gaps[k][1] += g
+    print("idle gaps > 20 us (count, total us) before:", {k: (v[0], round(v[1])) for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:8]})
     # glue launches inside the denoise loop (between two unipc steps) vs outside it, by (kernel, grid)
     inner = collections.Counter()
     for a, b in zip(steps[2 * n:-1], steps[2 * n + 1:]):
