@@ -404,8 +404,17 @@ def test_wan14b_width_fp8_gemm_matches_e4m3_oracle(hip_lib, parity):
     outga = model(lat.cuda(), t.cuda(), text.cuda())[0].clone()
     refga = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_gemm=True, fp8_attn=True)
     r1, r2, shift = _rel(outg, refg), _rel(outga, refga), _rel(outga, out16)
-    parity("dit_14B_width_fp8_gemm", rel_vs_e4m3_oracle=r1, rel_with_fp8_attention_vs_e4m3_oracle=r2, rel_fp8_modes_vs_bf16_mode=shift)
-    print(f"14B-width fp8-GEMM forward: rel vs e4m3 oracle {r1:.2e} (+fp8 attention {r2:.2e}); fp8 modes vs bf16 mode {shift:.2e}")
+    # The e4m3 quantiser between the layers is discontinuous: how far does the ORACLE move from itself when its input carries rounding-level
+    # noise (5e-4 relative, then re-rounded to bf16 - what separates any two bf16 implementations after one layer)?  That is the floor two
+    # restatements of this mode can agree to; the bf16 mode under the same noise is shown beside it.
+    latp = (lat.float() * (1 + 1e-3 * torch.randn(lat.shape, generator=g))).to(torch.bfloat16)
+    floor8 = _rel(O.dit_forward(sd, ocfg, latp.float(), t, text, emulate_bf16=True, fp8_gemm=True), refg)
+    floor16 = _rel(O.dit_forward(sd, ocfg, latp.float(), t, text, emulate_bf16=True), O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True))
+    parity("dit_14B_width_fp8_gemm", rel_vs_e4m3_oracle=r1, rel_with_fp8_attention_vs_e4m3_oracle=r2, rel_fp8_modes_vs_bf16_mode=shift,
+           oracle_e4m3_mode_moves_under_rounding_level_input_noise=floor8, oracle_bf16_mode_moves_under_the_same_noise=floor16)
+    print(f"14B-width fp8-GEMM forward: rel vs e4m3 oracle {r1:.2e} (+fp8 attention {r2:.2e}); fp8 modes vs bf16 mode {shift:.2e}; the e4m3 oracle "
+          f"moves {floor8:.2e} under 5e-4 input noise (the bf16 oracle {floor16:.2e})")
+    assert r1 < 2.0 * floor8 and r2 < 2.0 * floor8, (r1, r2, floor8)   # measured 3.2e-2 against a 3.3e-2 self-distance: conditioning, not a kernel error
     # Two pipelines with a discontinuous quantiser between their layers: a 1-ulp bf16 difference in an activation near an e4m3 tie
     # moves that element by a whole e4m3 step (2^-3 relative), so ~3 % of the quantised elements differ between kernel path and
     # oracle and the forward can only be bounded to a few e-2 here.  The GEMM itself is pinned on identical quantised operands to
