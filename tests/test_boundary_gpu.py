@@ -225,9 +225,11 @@ inp = torch.arange(1 << 16, device="cuda", dtype=torch.float32)
 out = torch.zeros(1, 1 << 16, device="cuda")
 grp.all_gather(out, inp).wait()          # eager warm-up: communicator set-up must not happen under capture
 torch.cuda.synchronize()
+import time
+time.sleep(0.3)                          # the RCCL watchdog retires the eager collective (it polls every ~100 ms) ...
 out.zero_()
 g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
+with torch.cuda.graph(g, capture_error_mode="thread_local"):   # ... and may keep polling while THIS thread captures (GraphedWanDiT does the same)
     grp.all_gather(out, inp).wait()
     y = out * 2
 ok = []
@@ -243,7 +245,8 @@ dist.destroy_process_group()
 
 def test_rccl_all_gather_is_capturable_in_a_hipgraph(hip_lib, tmp_path):
     """DistGroup.all_gather (async RCCL all_gather_into_tensor + wait) inside a captured hipGraph on a one-rank communicator: the replay
-    must re-run the collective on the current contents of its input.  What GraphedWanDiT(capture_sp=True) relies on; the multi-rank
+    must re-run the collective on the current contents of its input.  (Captured thread-locally after the watchdog retired the warm-up
+    collective: under the default global capture mode the watchdog thread's event poll aborted 2 of 12 runs.)  What GraphedWanDiT(capture_sp=True) relies on; the multi-rank
     form runs inside test_rccl_scene_parallel_denoise_matches_single_gpu whenever more than one GPU is visible."""
     import os, subprocess, sys, json
     from pathlib import Path

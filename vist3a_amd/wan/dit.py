@@ -608,7 +608,16 @@ class GraphedWanDiT:
             self.dit.forward(sx, st, text, sp=sp)  # eager warm-up: workspaces, kernel attributes, rope tables (and the communicator)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            kw = {}
+            if sp is not None:
+                # torch.distributed's RCCL watchdog thread polls the events of the eager warm-up's collectives every ~100 ms.  Under the
+                # default GLOBAL capture mode such a query from another thread while this thread captures aborts the process ("operation not
+                # permitted on an event last recorded in a capturing stream": 2 of 12 runs on MI355X / torch 2.10).  Let the watchdog retire
+                # the finished work first and capture thread-locally - either alone measured 0 of 12.
+                import time
+                time.sleep(0.3)
+                kw = dict(capture_error_mode="thread_local")
+            with torch.cuda.graph(g, **kw):
                 out = self.dit.forward(sx, st, text, sp=sp)[0]
             ent = self._graphs[key] = (g, sx, st, out, sp)   # (the group stays referenced: its id is part of the key)
         g, sx, st, out = ent[:4]
