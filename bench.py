@@ -133,6 +133,42 @@ def coop_requested(a, world):
     return a.parallel == "scene" and world > 1
 
 
+def sustained_clock(load, device_index, samples=4):
+    """Median shader clock / socket power rocm-smi reports while `load()` (one untimed scene) is repeated on the GPU."""
+    import re
+    import subprocess
+    import threading
+    got = []
+
+    def sampler():
+        time.sleep(0.4)   # the scene is in its denoise loop by then
+        for _ in range(samples):
+            try:
+                r = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20)
+                card = next(iter(json.loads(r.stdout).values()))
+                mhz = [int(re.search(r"(\d+)\s*Mhz", str(v), re.I).group(1)) for k, v in card.items() if "sclk" in k.lower() and re.search(r"\d+\s*Mhz", str(v), re.I)]
+                watts = [float(v) for k, v in card.items() if "power (w)" in k.lower()]
+                if mhz and watts:
+                    got.append((mhz[0], watts[0]))
+            except Exception:
+                pass
+
+    th = threading.Thread(target=sampler)
+    th.start()
+    n = 0
+    while th.is_alive() and n < 8:
+        load()
+        torch.cuda.synchronize()
+        n += 1
+    th.join()
+    if not got:
+        return None
+    got.sort()
+    mhz, watts = got[len(got) // 2][0], sorted(w for _, w in got)[len(got) // 2]
+    return {"sclk_mhz": mhz, "socket_power_w": watts, "samples": len(got), "scenes_run": n,
+            "note": "untimed extra; the MFMA roof at this clock is 2500 x sclk / 2400 TFLOP/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +360,9 @@ def main():
         box = {"gemm_8192x1536x1536_us": round(g_us, 1), "self_attention_2x12x4096_us": round(a_us, 1),
                "note": "untimed extras: best of 4 x 20 back-to-back launches on seeded data; the same launches read 38-41 / 184-192 us across the boxes of round 3"}
         del xa, xw, qb_, kb_, vtb, ob
+        # what the boxes differ in: the shader clock the firmware sustains under THIS load (the roofline's 2.5 PFLOP/s is quoted at 2.4 GHz).
+        # rocm-smi is sampled from a thread while untimed extra scenes run; any failure leaves the field null.
+        box["clock_under_load"] = None if coop else sustained_clock(lambda: scene(a.steps), local)
     if rank == 0:
         ps = probe.summary()
         ach = ps["flops_per_launch"] / (ps["avg_ms"] * 1e-3) / 1e12 if ps["launches"] else 0.0
@@ -375,6 +414,11 @@ def main():
                          "launches_timed": ps["launches"], "launch_sampling": "every 7th launch of the symbol in the last timed scene", "avg_launch_ms": round(ps["avg_ms"], 4),
                          "flops_per_launch": ps["flops_per_launch"]},
         }
+        clk = (box or {}).get("clock_under_load")
+        if clk:   # the same achieved rate against the roof at the clock the box actually held (information beside `frac`, which stays on the guide's peak)
+            pk = (FP8_MFMA_PEAK_TFLOPS if f8 else BF16_MFMA_PEAK_TFLOPS) * clk["sclk_mhz"] / 2400.0
+            line["roofline"]["frac_at_sustained_clock"] = round(ach / pk, 4)
+            line["roofline"]["sustained_clock_note"] = f"sclk {clk['sclk_mhz']} MHz at {clk['socket_power_w']:.0f} W under the scene's load: roof {pk:.0f} TFLOP/s"
         if world == 1 and not a.no_cpu_baseline and a.cpu_baseline != "none":
             line["cpu_baseline"] = cpu_baseline(cfg, a.cpu_baseline)
         print(json.dumps(line), flush=True)
