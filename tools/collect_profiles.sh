@@ -28,6 +28,7 @@ python tools/sp_rank_time.py 14b 2>/dev/null | tail -8 > $O/prof_sp_rank_time_14
 python tools/gemm_sweep.py 6,8,7 0,1,2,3,4,8 2>/dev/null | grep "^{" > $O/prof_gemm_sweep.jsonl
 python tools/gemm_fp8_time.py 2>/dev/null | grep "^{" > $O/prof_gemm_fp8.jsonl
 python tools/attn_time.py 2x12x4096 2x12x6144 2>/dev/null | grep '^{' > $O/prof_attn_time.jsonl
+python tools/xprobs_time.py 2>/dev/null | grep '^{' > $O/prof_xprobs_time.jsonl
 python tools/conv_sweep.py 2>/dev/null | tail -2 > $O/prof_conv_sweep.txt
 python tools/vae_time.py 2>/dev/null | tail -2 > $O/prof_vae_time.jsonl
 python tools/recon_time.py 2>/dev/null | tail -2 > $O/prof_recon_time.jsonl
