@@ -173,10 +173,6 @@ __global__ __launch_bounds__(256, 2) void xattn_probs_kernel(const XaP p) {
   }
 }
 
-#ifndef V3A_XP_UPW
-#define V3A_XP_UPW 0
-#endif
-
 }  // namespace
 
 extern "C" int v3a_xattn_probs_bf16(const v3a_xattn_probs_args* a, void* stream) {
@@ -202,7 +198,7 @@ extern "C" int v3a_xattn_probs_bf16(const v3a_xattn_probs_args* a, void* stream)
   // units per wave: 1 up to 2048 workgroups (the production launch, 2 x 12 heads x 4096 queries = 768 workgroups = 3 per CU, measured 14.0 us
   // against 15.4 / 15.7 at 2 / 4 units per wave, whose 384 / 192 workgroups load the CUs unevenly); beyond that a wave walks several
   // units with the next unit's Q in flight under the current one and a head's keys are read once per 128 upw queries
-  int upw = V3A_XP_UPW > 0 ? V3A_XP_UPW : (int)(((long)a->B * a->H * nsb + 4 * 2048 - 1) / (4 * 2048));
+  int upw = (int)(((long)a->B * a->H * nsb + 4 * 2048 - 1) / (4 * 2048));
   upw = upw < 1 ? 1 : (upw > 8 ? 8 : upw);
   while (upw > 1 && (nsb + 4 * upw - 1) / (4 * upw) == (nsb + 4 * (upw - 1) - 1) / (4 * (upw - 1))) --upw;   // no longer walk than the split needs
   p.upw = upw;
