@@ -248,16 +248,20 @@ struct LinP {
   int M, N, K, ldx, ldy, ldr, act;
 };
 // One wave per NPW consecutive outputs: every x fragment is used against NPW weight rows (with one output per wave the 13 activation
-// loads per 16-byte weight load, not the weight stream, set the pace: 0.7 TB/s).  Per output the k-order of the partial sums is unchanged.
-// Round 4: the activations of a K chunk (M rows x KC floats, <= 52 KB) are staged ONCE per workgroup in LDS and read from there by its four
-// waves.  Before, every wave re-read all of x (13 x 8 KB at the camera trunk's K = 2048) through L1 / L2 - 3072 waves x 106 KB = 326 MB of
-// L2 traffic beside the 50 MB qkv weight: the kernel ran at 0.9 TB/s of weight stream.  Same arithmetic, same summation order.
-template <int MAXM, int NPW, int KC>
+// loads per 16-byte weight load, not the weight stream, set the pace: 0.7 TB/s).  The activations are staged per workgroup in LDS and read
+// from there by its four waves (round 4; before, every wave re-read all of x through L1 / L2: 326 MB of L2 traffic beside the 50 MB qkv
+// weight).  Late round 4: K is walked in chunks of 256 (one 16-byte weight load per lane and row); the chunk's activations arrive by 16-byte
+// LDS-DMA in a double buffer of only 2 x M KB - the first form's 52 KB chunk limited a CU to two or three workgroups, and what this kernel
+// needs is loads in flight - and the weights of chunk c + 1 are requested before the FMAs of chunk c.  The host picks NPW so that the
+// workgroups fill whole rounds of 256 CUs (N = 6144: 3 -> 512 workgroups instead of 384; N = 2048: 2 -> 256 instead of 128).  The sum of
+// an output runs over k in index order within a lane (explicit FMAs: the same bits from every instantiation), then across the lanes.
+template <int MAXM, int NPW>
 __global__ __launch_bounds__(256) void linear_f32_kernel(const LinP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sx = (float*)smem;                                   // [M][KC]
+  constexpr int KC = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x [M][KC] floats
   const int lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NPW;   // (a wave past N still takes part in the staging and the barriers)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = (blockIdx.x * 4 + wave) * NPW;   // (a wave past N still takes part in the staging and the barriers)
   float acc[NPW][MAXM];
 #pragma unroll
   for (int j = 0; j < NPW; ++j)
@@ -265,28 +269,45 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const LinP p) {
     for (int m = 0; m < MAXM; ++m) acc[j][m] = 0.f;
   const float* wr[NPW];
 #pragma unroll
-  for (int j = 0; j < NPW; ++j) wr[j] = p.w + (size_t)min(n0 + j, p.N - 1) * p.K;   // (rows past N are computed and dropped)
-  for (int k0 = 0; k0 < p.K; k0 += KC) {
-    const int kc = min(KC, p.K - k0);                          // K % 4 == 0
-    if (k0) __syncthreads();
-    for (int i = threadIdx.x * 4; i < p.M * kc; i += 1024) {
-      const int m = i / kc, kk = i - m * kc;
-      *(f32x4*)(sx + m * KC + kk) = *(const f32x4*)(p.x + (size_t)m * p.ldx + k0 + kk);
-    }
-    __syncthreads();
-    for (int kk = lane * 4; kk < kc; kk += 256) {
-      f32x4 wv[NPW];
+  for (int j = 0; j < NPW; ++j) wr[j] = p.w + (size_t)min(n0 + j, p.N - 1) * p.K + lane * 4;   // (rows past N are computed and dropped)
+  const int nchunks = (p.K + KC - 1) / KC;
+  auto stage = [&](int c) {   // one 1-KiB piece per row; lanes past the end of K re-read the row's last float4 (their slots are never read)
+    const int k0 = c * KC, kc = min(KC, p.K - k0);     // K % 4 == 0
+    float* sb = (float*)smem + (size_t)(c & 1) * p.M * KC;
+    for (int m = wave; m < p.M; m += 4) glds16(p.x + (size_t)m * p.ldx + k0 + min(lane * 4, kc - 4), sb + m * KC);
+  };
+  auto loadw = [&](int c, f32x4 (&wv)[NPW]) {
+    if (c * KC + lane * 4 < p.K) {
 #pragma unroll
-      for (int j = 0; j < NPW; ++j) wv[j] = *(const f32x4*)(wr[j] + k0 + kk);
+      for (int j = 0; j < NPW; ++j) wv[j] = *(const f32x4*)(wr[j] + c * KC);
+    }
+  };
+  f32x4 wv[NPW], wn[NPW];
+#pragma unroll
+  for (int j = 0; j < NPW; ++j) wv[j] = wn[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  stage(0);
+  loadw(0, wv);
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // chunk c has landed; everyone is done with the other buffer
+    if (c + 1 < nchunks) {
+      stage(c + 1);
+      loadw(c + 1, wn);
+    }
+    if (c * KC + lane * 4 < p.K) {
+      const float* sx = (const float*)smem + (size_t)(c & 1) * p.M * KC + lane * 4;
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) {
         if (m < p.M) {
-          const f32x4 xv = *(const f32x4*)(sx + m * KC + kk);
+          const f32x4 xv = *(const f32x4*)(sx + m * KC);
 #pragma unroll
-          for (int j = 0; j < NPW; ++j) acc[j][m] += wv[j][0] * xv[0] + wv[j][1] * xv[1] + wv[j][2] * xv[2] + wv[j][3] * xv[3];
+          for (int j = 0; j < NPW; ++j)
+            acc[j][m] = __builtin_fmaf(wv[j][3], xv[3], __builtin_fmaf(wv[j][2], xv[2], __builtin_fmaf(wv[j][1], xv[1], __builtin_fmaf(wv[j][0], xv[0], acc[j][m]))));
         }
       }
     }
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) wv[j] = wn[j];
   }
 #pragma unroll
   for (int j = 0; j < NPW; ++j) {
@@ -307,6 +328,12 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const LinP p) {
       p.y[(size_t)lane * p.ldy + n] = v;
     }
   }
+}
+
+template <int MAXM, int NPW>
+int launch_linear_f32(const LinP& p, void* stream) {
+  hipLaunchKernelGGL((linear_f32_kernel<MAXM, NPW>), dim3((unsigned)((p.N + 4 * NPW - 1) / (4 * NPW))), dim3(256), (size_t)2 * p.M * 256 * 4, (hipStream_t)stream, p);
+  return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
 // fp32 attention over a handful of tokens (camera-head trunk: S views x heads, vggt/layers/attention.py:49-80 without
@@ -406,10 +433,25 @@ extern "C" int v3a_linear_f32(const float* x, const float* w, const float* bias,
   if (!x || !w || !y) return V3A_ERR_ARG;
   if (M <= 0 || M > 32 || N <= 0 || K <= 0 || K % 4 || ldx % 4) return V3A_ERR_SHAPE;
   LinP p{x, w, bias, y, residual, gamma, M, N, K, ldx, ldy, ldr, act};
-  // LDS: M rows x KC floats of x per workgroup (16 x 1024 x 4 B = 64 KB, 32 x 512 x 4 B = 64 KB)
-  if (M <= 16) hipLaunchKernelGGL((linear_f32_kernel<16, 4, 1024>), dim3((N + 15) / 16), dim3(256), (size_t)M * 1024 * 4, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((linear_f32_kernel<32, 2, 512>), dim3((N + 7) / 8), dim3(256), (size_t)M * 512 * 4, (hipStream_t)stream, p);
-  return LAUNCH_OK();
+  // outputs per wave: the count whose workgroups (4 waves) come closest to whole rounds of 256 CUs; ties go to the larger count (more
+  // reuse of every staged activation)
+  const int maxnpw = M <= 16 ? 4 : 2;
+  int best = 1;
+  double beff = -1.0;
+  for (int npw = 1; npw <= maxnpw; ++npw) {
+    const long wgs = (N + 4 * npw - 1) / (4 * npw);
+    const double eff = (double)wgs / (double)(((wgs + 255) / 256) * 256);
+    if (eff >= beff - 1e-9) { beff = eff; best = npw; }
+  }
+  if (M <= 16) {
+    switch (best) {
+      case 4: return launch_linear_f32<16, 4>(p, stream);
+      case 3: return launch_linear_f32<16, 3>(p, stream);
+      case 2: return launch_linear_f32<16, 2>(p, stream);
+      default: return launch_linear_f32<16, 1>(p, stream);
+    }
+  }
+  return best == 2 ? launch_linear_f32<32, 2>(p, stream) : launch_linear_f32<32, 1>(p, stream);
 }
 
 extern "C" int v3a_attention_small_f32(const float* qkv, float* out, int S, int H, int hd, float scale, void* stream) {
