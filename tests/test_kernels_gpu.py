@@ -792,6 +792,7 @@ XATTN_CASES = [
     ("one_key_tile", 2, 12, 1000, 40, 48, True),          # <= 64 keys: the one-tile instantiation; ragged last query block
     ("full_128_keys", 1, 40, 512, 128, 128, False),       # Wan-14B head count, both key tiles full, no bias
     ("two_heads_pad32", 2, 2, 96, 24, 32, True),          # the test models' geometry (H = 2: keys padded to 32 so that H * Lkp % 64 == 0)
+    ("pad_beyond_key_tiles", 1, 5, 200, 10, 64, True),    # an odd head count pads 10 keys to 64: the zero columns lie beyond the last 32-key sub-tile that holds a key
     ("two_units_per_wave", 2, 12, 16424, 73, 80, True),   # > 2048 workgroups of one unit per wave: every wave walks two 32-query units (ragged end)
 ]
 

@@ -44,7 +44,7 @@ struct XaP {
 constexpr int D = 128, KROWB = D * 2, NW = 4;
 constexpr float LOG2E = 1.4426950408889634f;
 
-template <int NU>   // 32-key sub-tiles: Nk <= 32 NU
+template <int NU>   // 32-key sub-tiles: Nk <= Lkp <= 32 NU
 __global__ __launch_bounds__(256, 2) void xattn_probs_kernel(const XaP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [32 NU keys][256 B] | row factors [4 upw 32] | key table [32 NU]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -193,7 +193,7 @@ extern "C" int v3a_xattn_probs_bf16(const v3a_xattn_probs_args* a, void* stream)
     if (a->q_sumsq_parts <= 0 || a->q_sumsq_parts % 4) return V3A_ERR_SHAPE;
     p.qsq = a->q_row_sumsq; p.qparts = a->q_sumsq_parts; p.q_eps = a->q_eps; p.inv_dim = 1.0f / (float)(a->H * 128);
   }
-  const int nu = (a->Nk + 31) / 32;
+  const int nu = (a->Lkp + 31) / 32;   // sub-tiles over the PADDED row: every column of [0, Lkp) is written (zeros beyond the last key)
   const int nsb = (a->Nq + 31) / 32;
   // units per wave: 1 up to 2048 workgroups (the production launch, 2 x 12 heads x 4096 queries = 768 workgroups = 3 per CU, measured 14.0 us
   // against 15.4 / 15.7 at 2 / 4 units per wave, whose 384 / 192 workgroups load the CUs unevenly); beyond that a wave walks several
