@@ -792,7 +792,6 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
     if (a->D != 64 || a->rel_bias_center < a->Nq - 1 || a->rel_bias_stride < a->rel_bias_center + a->Nk) return V3A_ERR_SHAPE;
     return launch_attn<64, 4, true, false, false>(p, a->B, stream);
   }
-  static const bool two_per_cu = getenv("V3A_ATTN_OCC2") != nullptr;  // A/B switch for the older 2-workgroup schedule
   p.kbias = a->key_bias; p.kbias_stride = a->key_bias_stride; p.kbias_first = a->key_bias_first > 0 ? a->key_bias_first : 0;
   p.kv_seg = a->kv_seg; p.k_seg = a->k_seg_stride; p.vt_seg = a->vt_seg_stride;
   if (a->kv_seg < 0 || (a->kv_seg > 0 && (a->kv_seg % 64 || a->Nk % a->kv_seg || a->D != 128 || a->rel_bias || a->key_bias ||
@@ -809,7 +808,6 @@ extern "C" int v3a_attention_fwd_bf16(const v3a_attn_args* a, void* stream) {
     return launch_attn<128, 4, false, true, true>(p, a->B, stream);
   }
   if (a->D == 128) {
-    if (two_per_cu) return launch_attn<128, 4, false, false, false>(p, a->B, stream);
     // a sequence-parallel shard (Nq = N / P queries against all N keys) has too few 128-query blocks to occupy 256 CUs: 64-query
     // workgroups double the count; per-wave arithmetic and key order are unchanged, so the output stays bit-identical
     const long wgs4 = (long)a->B * a->H * ((a->Nq + 127) / 128) * p.kv_split;

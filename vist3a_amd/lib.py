@@ -8,7 +8,7 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = Path(os.environ.get("V3A_LIB") or _HERE / "libvist3a_hip.so")   # V3A_LIB: an experiment build of the same ABI (tools/abl_build.sh)
+LIB_PATH = Path(os.environ.get("V3A_LIB") or _HERE / "libvist3a_hip.so")   # V3A_LIB: an experiment build of the same ABI (tools/variant_build.sh)
 
 V3A_OK = 0
 ERRORS = {-1: "V3A_ERR_ARG", -2: "V3A_ERR_SHAPE", -3: "V3A_ERR_LAUNCH", -4: "V3A_ERR_WORKSPACE"}
