@@ -79,15 +79,31 @@ __device__ __forceinline__ float erf_as(float x) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
+// Wave-wide sum / maximum, the same value in every lane.  DPP cross-lane operands instead of six __shfl_xor steps: hipcc turns a
+// shuffle into ds_bpermute_b32 (address arithmetic + an LDS-crossbar round trip of ~100 cycles), and a row-normalisation wave has one or
+// two of these reductions between its loads and its stores - ~1 us of a 10 us launch.  Order of the sum: lanes of a quad, quads of a
+// half row, half rows, rows 0+1 / 2+3, halves - fixed, so the result is deterministic (it is not the butterfly's association).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f32<0xB1>(0.f, v);          // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(0.f, v);          // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(0.f, v);         // row_half_mirror
+  v += dpp_f32<0x140>(0.f, v);         // row_mirror: every lane of a 16-lane row holds the row's sum
+  v += dpp_f32<0x142, 0xA>(0.f, v);    // row_bcast:15 into rows 1 and 3
+  v += dpp_f32<0x143, 0xC>(0.f, v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f32<0xB1>(v, v));
+  v = fmaxf(v, dpp_f32<0x4E>(v, v));
+  v = fmaxf(v, dpp_f32<0x141>(v, v));
+  v = fmaxf(v, dpp_f32<0x140>(v, v));
+  v = fmaxf(v, dpp_f32<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_f32<0x143, 0xC>(v, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Sum of `parts` (% 4 == 0) consecutive floats in index order with the loads in flight TOGETHER: the partial sums of squares a GEMM epilogue
