@@ -262,9 +262,13 @@ def test_batched_forward_assembles_scenes_like_the_reference(hip_lib):
     m = AnySplatStitched(AnySplatWeights(dict(sd), ReconCfg(**kw, voxelize=True, voxel_size=0.05)), "enc_blocks_2", "cuda")
     lat, img = g["latent"].cuda(), g["image"].cuda()
     gen = torch.Generator().manual_seed(5)
-    lat2 = torch.cat([lat, lat + 0.3 * torch.randn(lat.shape, generator=gen).cuda()], 0)
-    img2 = torch.cat([img, (img * 0.7).clamp(-1, 1)], 0)
     singles = []
+    for amp in (0.3, 0.6, 1.0, 1.5):   # the second scene must fuse to a DIFFERENT voxel count (the padding branch): first perturbation that does
+        lat2 = torch.cat([lat, lat + amp * torch.randn(lat.shape, generator=gen).cuda()], 0)
+        img2 = torch.cat([img, (img * (1.0 - 0.3 * amp)).clamp(-1, 1)], 0)
+        counts = [m(lat2[b:b + 1], img2[b:b + 1], train=False).gaussians.means.shape[1] for b in range(2)]
+        if counts[0] != counts[1]:
+            break
     for b in range(2):
         o = m(lat2[b:b + 1], img2[b:b + 1], train=False)
         singles.append({k: getattr(o.gaussians, k).clone() for k in ("means", "covariances", "harmonics", "opacities", "scales", "rotations")}

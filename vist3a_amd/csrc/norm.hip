@@ -21,18 +21,43 @@ struct LnP {
   int ig, is, io, og, os, oo;   // row remaps: in row = m + (m/ig)*is + io (ig>0), out row likewise
   int rms;                      // 1: no mean subtraction
   float* y_scale;               // non-null: e4m3 output with per-row dynamic scale
+  int stage;                    // 1: the workgroup's rows share their per-column parameters (AdaLN scale | shift of one batch item, else the
+                                //    affine weight | bias): staged once per workgroup in LDS (2 x ceil(d / 256) KiB) by LDS-DMA
 };
+
+// Per-column parameters of a row-normalisation workgroup (4 waves = 4 rows) -> LDS: two arrays of d floats as whole 1-KiB DMA pieces (lanes
+// past d re-read the array's last float4; a null second array repeats the first and is never read).  Issued BEFORE the row loads: the wave's
+// own wait for its row covers its pieces (in-order vmcnt), the workgroup barrier the other waves'.  Read back after the reductions at LDS
+// latency - loaded from L2 there (twelve 16-byte loads per lane in three dependent groups, there being no registers to hold them across the
+// reductions at 8 waves per SIMD) they cost the AdaLN LayerNorm 1.4 of its 10.3 us.
+__device__ __forceinline__ void stage_params(const float* a0, const float* a1, int d, char* lds, int wave, int lane, int narr = 2) {
+  const int np = (d + 255) >> 8;
+  for (int pc = wave; pc < narr * np; pc += 4) {
+    const int arr = pc >= np, q = pc - arr * np;
+    const float* src = (arr && a1) ? a1 : a0;
+    glds16(src + min(q * 256 + lane * 4, d - 4), lds + (size_t)pc * 1024);
+  }
+}
 
 // F8OUT: e4m3 output with per-row scales (a separate instantiation: its extra live registers would cost the bf16 kernel a wave per
 // SIMD, and 8192 rows are exactly 8 waves per SIMD - one round)
 template <int CPL, bool F8OUT = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
+  extern __shared__ __attribute__((aligned(16))) char lnsm[];
   const int lane = threadIdx.x & 63;
-  const int row0 = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row0 >= p.M) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rowu = blockIdx.x * 4 + wave;
+  if (!p.stage && rowu >= p.M) return;            // (staging workgroups keep every wave for the barrier: a wave past M recomputes row M - 1)
+  const bool live_row = rowu < p.M;
+  const int row0 = live_row ? rowu : p.M - 1;
   const size_t row = p.ig > 0 ? (size_t)row0 + (size_t)(row0 / p.ig) * p.is + p.io : (size_t)row0;
   const size_t orow = p.og > 0 ? (size_t)row0 + (size_t)(row0 / p.og) * p.os + p.oo : (size_t)row0;
   const int nch = p.d >> 3;
+  if (p.stage) {   // staged arrays: AdaLN (scale, shift) when modulated, else the affine (weight, bias)
+    const size_t mo = (size_t)((blockIdx.x * 4) / p.rpb) * p.mstride;
+    if (p.scale) stage_params(p.scale + mo, p.shift + mo, p.d, lnsm, wave, lane);
+    else stage_params(p.w, p.b, p.d, lnsm, wave, lane);
+  }
   float v[CPL][8];
   float sum = 0.f;
   // All of the row's loads are issued back to back, branch-free (chunks past the row end read the last chunk and are zeroed):
@@ -74,6 +99,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)p.d + p.eps);
   const size_t moff = (size_t)(row0 / p.rpb) * p.mstride;
+  if (p.stage) {
+    __syncthreads();                              // every wave's parameter pieces have landed (its own: in order before its row)
+    if (!live_row) return;
+  }
+  const bool lds_mod = p.stage && p.scale, lds_aff = p.stage && !p.scale;
+  const int apitch = ((p.d + 255) >> 8) << 8;     // floats between the two staged arrays
+  // 8 consecutive parameters of chunk c: from the staged copy (arr = 0 / 1) or from global memory
+  auto ld8 = [&](bool staged, int arr, const float* g, int c, f32x4& a, f32x4& b) {
+    if (staged) {   // (explicit LDS address space: through a generic pointer hipcc emits flat loads for BOTH branches)
+      const LDS_AS f32x4* l = (const LDS_AS f32x4*)(lnsm + (size_t)(arr * apitch + c * 8) * 4);
+      a = l[0]; b = l[1];
+    } else {
+      a = *(const f32x4*)(g + c * 8); b = *(const f32x4*)(g + c * 8 + 4);
+    }
+  };
   float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
@@ -83,18 +123,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnP p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd;
     if (p.w) {
-      const f32x4 w0 = *(const f32x4*)(p.w + c * 8), w1 = *(const f32x4*)(p.w + c * 8 + 4);
+      f32x4 w0, w1;
+      ld8(lds_aff, 0, p.w, c, w0, w1);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[e] *= w0[e]; o[4 + e] *= w1[e]; }
       if (p.b) {
-        const f32x4 b0 = *(const f32x4*)(p.b + c * 8), b1 = *(const f32x4*)(p.b + c * 8 + 4);
+        f32x4 b0, b1;
+        ld8(lds_aff, 1, p.b, c, b0, b1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { o[e] += b0[e]; o[4 + e] += b1[e]; }
       }
     }
     if (p.scale) {
-      const f32x4 s0 = *(const f32x4*)(p.scale + moff + c * 8), s1 = *(const f32x4*)(p.scale + moff + c * 8 + 4);
-      const f32x4 h0 = *(const f32x4*)(p.shift + moff + c * 8), h1 = *(const f32x4*)(p.shift + moff + c * 8 + 4);
+      f32x4 s0, s1, h0, h1;
+      ld8(lds_mod, 0, p.scale + moff, c, s0, s1);
+      ld8(lds_mod, 1, p.shift + moff, c, h0, h1);
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[e] = o[e] * (1.f + s0[e]) + h0[e]; o[4 + e] = o[4 + e] * (1.f + s1[e]) + h1[e]; }
     }
@@ -142,16 +185,33 @@ struct RmsP {
   int M, d, ldx, ldy, hd, tokens_per_batch;
   float eps;
   float f8_inv_scale;   // > 0: y is e4m3 BYTES [M][ldy], value = e4m3(clamp(bf16(result) * f8_inv_scale)) (operands of the fp8 attention)
+  int stage;            // 1: the weight is staged once per workgroup in LDS (stage_params)
 };
 
 template <int CPL, bool F8OUT = false>
 __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const RmsP pin) {
   RmsP p = pin;
   if (blockIdx.y) { p.x += (size_t)p.d * 2; p.y += (size_t)p.d * (F8OUT ? 1 : 2); p.w = p.w2; }   // the k half of a fused q|k projection
+  extern __shared__ __attribute__((aligned(16))) char lnsm[];
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= p.M) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rowu = blockIdx.x * 4 + wave;
+  if (!p.stage && rowu >= p.M) return;
+  const bool live_row = rowu < p.M;
+  const int row = live_row ? rowu : p.M - 1;
   const int nch = p.d >> 3;
+  if (p.stage) stage_params(p.w, nullptr, p.d, lnsm, wave, lane, 1);
+  // the rotary factors of a lane's chunks: chunk c = lane + 64 i sits at position c % (hd / 8) of its head, which is the same for every i
+  // when hd / 8 divides 64 (hd = 128: 16) - one pair of loads per lane, issued with the row's loads, instead of one pair per chunk behind
+  // the reduction
+  const int tok = row % p.tokens_per_batch;
+  const int cph = p.hd >> 3;  // chunks per head
+  const bool rope_once = p.rope && (64 % cph) == 0;
+  f32x4 rr0 = {0.f, 0.f, 0.f, 0.f}, rr1 = rr0;
+  if (rope_once) {
+    const float* rp = p.rope + ((size_t)tok * (p.hd >> 1) + (size_t)(lane % cph) * 4) * 2;
+    rr0 = *(const f32x4*)rp; rr1 = *(const f32x4*)(rp + 4);
+  }
   float v[CPL][8];
   float sq = 0.f;
   {   // branch-free, all loads in flight together (see layernorm_kernel)
@@ -167,21 +227,32 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(const RmsP pin) {
     }
   }
   const float rs = rsqrtf(wave_sum(sq) / (float)p.d + p.eps);
-  const int tok = row % p.tokens_per_batch;
-  const int cph = p.hd >> 3;  // chunks per head
+  if (p.stage) {
+    __syncthreads();                              // every wave's weight pieces have landed
+    if (!live_row) return;
+  }
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
     const int c = lane + i * 64;
     if (c >= nch) continue;
     float o[8];
     {
-      const f32x4 w0 = *(const f32x4*)(p.w + c * 8), w1 = *(const f32x4*)(p.w + c * 8 + 4);
+      f32x4 w0, w1;
+      if (p.stage) {
+        const LDS_AS f32x4* l = (const LDS_AS f32x4*)(lnsm + (size_t)c * 32);
+        w0 = l[0]; w1 = l[1];
+      } else {
+        w0 = *(const f32x4*)(p.w + c * 8); w1 = *(const f32x4*)(p.w + c * 8 + 4);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) { o[e] = v[i][e] * rs * w0[e]; o[4 + e] = v[i][4 + e] * rs * w1[e]; }
     }
     if (p.rope) {
-      const float* rp = p.rope + ((size_t)tok * (p.hd >> 1) + (size_t)(c % cph) * 4) * 2;
-      const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+      f32x4 r0 = rr0, r1 = rr1;
+      if (!rope_once) {
+        const float* rp = p.rope + ((size_t)tok * (p.hd >> 1) + (size_t)(c % cph) * 4) * 2;
+        r0 = *(const f32x4*)rp; r1 = *(const f32x4*)(rp + 4);
+      }
       const float cs[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -300,14 +371,14 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const SoftmaxP p) {
 
 }  // namespace
 
-#define DISPATCH_CPL(KERNEL, P, d, grid, stream)                                             \
+#define DISPATCH_CPL(KERNEL, P, d, grid, lds, stream)                                             \
   do {                                                                                       \
     const int cpl_ = ((d) / 8 + 63) / 64;                                                    \
-    if (cpl_ <= 1) hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), 0, (hipStream_t)stream, P); \
-    else if (cpl_ <= 2) hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), 0, (hipStream_t)stream, P); \
-    else if (cpl_ <= 3) hipLaunchKernelGGL(KERNEL<3>, grid, dim3(256), 0, (hipStream_t)stream, P); \
-    else if (cpl_ <= 4) hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, (hipStream_t)stream, P); \
-    else if (cpl_ <= 10) hipLaunchKernelGGL(KERNEL<10>, grid, dim3(256), 0, (hipStream_t)stream, P); \
+    if (cpl_ <= 1) hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), lds, (hipStream_t)stream, P); \
+    else if (cpl_ <= 2) hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), lds, (hipStream_t)stream, P); \
+    else if (cpl_ <= 3) hipLaunchKernelGGL(KERNEL<3>, grid, dim3(256), lds, (hipStream_t)stream, P); \
+    else if (cpl_ <= 4) hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), lds, (hipStream_t)stream, P); \
+    else if (cpl_ <= 10) hipLaunchKernelGGL(KERNEL<10>, grid, dim3(256), lds, (hipStream_t)stream, P); \
     else return V3A_ERR_SHAPE;                                                               \
   } while (0)
 
@@ -327,14 +398,18 @@ extern "C" int v3a_layernorm(const v3a_layernorm_args* a, void* stream) {
   p.y_scale = a->y_fp8_scale;
   if (p.y_scale && p.y_f32) return V3A_ERR_ARG;
   const dim3 grid((a->M + 3) / 4);
+  // per-column parameters staged in LDS when the 4 rows of a workgroup share them and the two arrays fit 16 KB (8 workgroups per CU stay resident)
+  const int np = (a->d + 255) / 256;
+  p.stage = ((p.scale && p.shift && p.rpb % 4 == 0) || (!p.scale && p.w)) && a->d >= 4 && 2 * np * 1024 <= 16384 && a->M >= 64;
+  const size_t lds = p.stage ? (size_t)2 * np * 1024 : 0;
   if (p.y_scale) {
     const int cpl = (a->d / 8 + 63) / 64;
-    if (cpl <= 3) hipLaunchKernelGGL((layernorm_kernel<3, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (cpl <= 10) hipLaunchKernelGGL((layernorm_kernel<10, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (cpl <= 3) hipLaunchKernelGGL((layernorm_kernel<3, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
+    else if (cpl <= 10) hipLaunchKernelGGL((layernorm_kernel<10, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
     else return V3A_ERR_SHAPE;
     return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
   }
-  DISPATCH_CPL(layernorm_kernel, p, a->d, grid, stream);
+  DISPATCH_CPL(layernorm_kernel, p, a->d, grid, lds, stream);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
@@ -352,14 +427,17 @@ extern "C" int v3a_rmsnorm_rope(const v3a_rmsnorm_rope_args* a, void* stream) {
   p.f8_inv_scale = a->y_fp8_scale > 0.f ? 1.0f / a->y_fp8_scale : 0.f;
   if (a->y_fp8_scale < 0.f || (a->y_fp8_scale > 0.f && a->y == a->x)) return V3A_ERR_ARG;   // (bytes cannot overwrite the bf16 input in place)
   const dim3 grid((a->M + 3) / 4, a->weight2 ? 2 : 1);
+  const int np = (a->d + 255) / 256;
+  p.stage = np * 1024 <= 16384 && a->M >= 64;   // the weight through LDS (<= 16 KB per workgroup: 8 workgroups per CU stay resident)
+  const size_t lds = p.stage ? (size_t)np * 1024 : 0;
   if (p.f8_inv_scale > 0.f) {   // (its own instantiations: the extra live registers would cost the bf16 kernels a wave per SIMD)
     const int cpl = (a->d / 8 + 63) / 64;
-    if (cpl <= 3) hipLaunchKernelGGL((rmsnorm_rope_kernel<3, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (cpl <= 10) hipLaunchKernelGGL((rmsnorm_rope_kernel<10, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    if (cpl <= 3) hipLaunchKernelGGL((rmsnorm_rope_kernel<3, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
+    else if (cpl <= 10) hipLaunchKernelGGL((rmsnorm_rope_kernel<10, true>), grid, dim3(256), lds, (hipStream_t)stream, p);
     else return V3A_ERR_SHAPE;
     return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
   }
-  DISPATCH_CPL(rmsnorm_rope_kernel, p, a->d, grid, stream);
+  DISPATCH_CPL(rmsnorm_rope_kernel, p, a->d, grid, lds, stream);
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
