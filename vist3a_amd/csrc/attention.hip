@@ -265,15 +265,17 @@ __global__ __launch_bounds__(NW * 64, V1 ? 3 : 2) void attn_fwd_kernel(const Att
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-    {   // max over the two lane halves: v_permlane32_swap instead of the ds_bpermute a shuffle compiles to (see attn_fwd_plain_kernel)
-#ifdef V3A_ATTN_BPERM
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#else
+    // max over the two lane halves: v_permlane32_swap instead of the ds_bpermute a shuffle compiles to (see attn_fwd_plain_kernel) - NOT in
+    // the two bias instantiations: with the asm statement beside their bias loops hipcc 7.2 spills 3.3 KB per lane (the cross-attention
+    // fallback launch went from 21 us to ~950 us; same fragility as the key-period mask below)
+#ifndef V3A_ATTN_BPERM
+    if constexpr (!RELB && !KBIAS) {
       float ma = mx, mb = mx;
       asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ma), "+v"(mb));
       mx = fmaxf(ma, mb);
+    } else
 #endif
-    }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     // Deferred rescale: m_run is the REFERENCE of the exponentials, not necessarily the running maximum.  It moves (and l / O are
     // rescaled) only when some lane's maximum outgrew it by more than 2^DEFER; until then p = 2^((s - m_run) c) <= 2^DEFER, which
     // costs bf16 no precision, and the 64 accumulator multiplies per tile are skipped (on random scores: every tile but the first
