@@ -141,3 +141,77 @@ def test_unmerged_lora_equals_merged_weights_in_fp32():
     plain = O.dit_forward(base, cfg, lat, t, text)
     rel = lambda x, y: ((x - y).norm() / y.norm()).item()
     assert rel(a, b) < 2e-6 and rel(a, plain) > 1e-2     # identical map; and the adapter really changes the output
+
+
+def test_rope_scores_depend_on_relative_grid_offsets_only():
+    """The published rotary scheme (complex multiplication of adjacent pairs, per-axis frequency blocks): the score of a query at grid
+    position p and a key at position p' is a function of p - p' alone - shifting both tokens by the same (dt, dh, dw) changes nothing, and
+    a shift along ONE axis changes only that axis' block of the inner product."""
+    cfg = O.WAN_1_3B
+    g = O.rope_for_grid(cfg, 6, 8, 8)                                  # [6*8*8, 64] complex
+    idx = lambda t, h, w: (t * 8 + h) * 8 + w
+    gen = torch.Generator().manual_seed(3)
+    q = torch.randn(1, 1, 1, 128, generator=gen, dtype=torch.float64)
+    k = torch.randn(1, 1, 1, 128, generator=gen, dtype=torch.float64)
+    def score(pq, pk):
+        a = O.apply_rope(q, g[idx(*pq)][None].to(torch.complex128))
+        b = O.apply_rope(k, g[idx(*pk)][None].to(torch.complex128))
+        return (a * b).sum().item()
+    base = score((1, 2, 3), (0, 5, 1))
+    for d in ((1, 0, 0), (0, 2, 0), (0, 0, 4), (3, 1, 2)):
+        moved = score((1 + d[0], 2 + d[1], 3 + d[2]), (0 + d[0], 5 + d[1], 1 + d[2]))
+        assert abs(moved - base) < 1e-9 * (1 + abs(base)), (d, moved, base)
+    assert abs(score((1, 2, 3), (1, 5, 1)) - base) > 1e-6               # ... and it does depend on the offset itself
+    # per-axis blocks: with only the h-block of q non-zero, moving the key along t or w is invisible
+    qh = torch.zeros_like(q)
+    qh[..., 44:86] = q[..., 44:86]                                      # pairs 22..42 = the 21 complex dims of the h axis
+    def score_h(pk):
+        a = O.apply_rope(qh, g[idx(1, 2, 3)][None].to(torch.complex128))
+        b = O.apply_rope(k, g[idx(*pk)][None].to(torch.complex128))
+        return (a * b).sum().item()
+    assert abs(score_h((0, 5, 1)) - score_h((4, 5, 6))) < 1e-9 and abs(score_h((0, 5, 1)) - score_h((0, 6, 1))) > 1e-6
+
+
+def test_forward_is_invariant_to_the_order_of_text_tokens_and_independent_across_the_batch():
+    """Cross-attention carries no position information on the text side (the rotary embedding is applied in the self-attention only), so
+    permuting the rows of encoder_hidden_states must not change the output; and batch items never mix (a batch of two = two batches of one)."""
+    cfg = TINY
+    sd = O.make_weights(cfg, seed=5)
+    gen = torch.Generator().manual_seed(6)
+    lat = torch.randn(2, 16, 2, 8, 8, generator=gen)
+    text = torch.randn(2, 12, cfg.text_dim, generator=gen)
+    t = torch.tensor([700, 300])
+    y = O.dit_forward(sd, cfg, lat, t, text)
+    perm = torch.randperm(12, generator=gen)
+    y_perm = O.dit_forward(sd, cfg, lat, t, text[:, perm])
+    assert torch.allclose(y, y_perm, atol=2e-5), (y - y_perm).abs().max()
+    for b in range(2):
+        yb = O.dit_forward(sd, cfg, lat[b:b + 1], t[b:b + 1], text[b:b + 1])
+        assert torch.allclose(y[b:b + 1], yb, atol=2e-5)
+    # ... while the latent tokens DO carry positions: rolling the latent along w is not a roll of the output
+    y_roll = O.dit_forward(sd, cfg, lat.roll(2, dims=-1), t, text)
+    assert not torch.allclose(y_roll.roll(-2, dims=-1), y, atol=1e-3)
+
+
+def test_adaln_modulation_enters_as_scale_shift_gate_in_the_published_order():
+    """scale_shift_table + time projection, chunked as (shift, scale, gate) for the self-attention and (shift, scale, gate) for the FFN:
+    with every gate at zero and the cross-attention silenced a block is the identity WHATEVER the shifts and scales are; a non-zero FFN gate
+    scales exactly the FFN branch (linear in the gate)."""
+    cfg = TINY
+    sd = O.make_weights(cfg, seed=8)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 32, cfg.dim, generator=gen)
+    ctx = torch.randn(1, 16, cfg.dim, generator=gen)
+    freqs = O.rope_for_grid(cfg, 2, 4, 4)
+    sd["blocks.0.attn2.to_out.0.weight"].zero_()
+    sd["blocks.0.attn2.to_out.0.bias"].zero_()
+    tproj = torch.randn(1, 6, cfg.dim, generator=gen)
+    tab = sd["blocks.0.scale_shift_table"]
+    tab[:, 2] = -tproj[:, 2]                                            # total self-attention gate = 0
+    tab[:, 5] = -tproj[:, 5]                                            # total FFN gate = 0
+    assert torch.allclose(O.block_forward(sd, cfg, 0, x, ctx, tproj, freqs, False), x, atol=1e-6)
+    tab[:, 5] = -tproj[:, 5] + 0.5
+    d1 = O.block_forward(sd, cfg, 0, x, ctx, tproj, freqs, False) - x
+    tab[:, 5] = -tproj[:, 5] + 1.5
+    d3 = O.block_forward(sd, cfg, 0, x, ctx, tproj, freqs, False) - x
+    assert d1.abs().max() > 1e-3 and torch.allclose(d3, 3.0 * d1, rtol=1e-4, atol=1e-5)

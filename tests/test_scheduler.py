@@ -63,3 +63,38 @@ def test_first_step_closed_form():
     want = (s1 / s0) * x - (1 - s1) * np.expm1(-h) * x0
     got = a.step(v, a.timesteps[0], x)[0]
     assert torch.allclose(got, want.float(), rtol=1e-4, atol=1e-5)
+
+
+def _gaussian_flow_error(make, steps, s=0.7, shift=1.0):
+    """Integrate the probability-flow ODE of rectified flow for Gaussian data x0 ~ N(0, s^2): the optimal velocity is linear,
+    v(x, sigma) = (sigma - (1 - sigma) s^2) / ((1 - sigma)^2 s^2 + sigma^2) x, and the exact flow keeps x / std(sigma) constant:
+    x(0) = x(sigma_0) s / sqrt((1 - sigma_0)^2 s^2 + sigma_0^2).  Returns the relative error of the sampler's end point."""
+    sch, step = make(shift, steps)
+    sig = sch.sigmas.double()
+    x = torch.tensor([[[[[1.0, -2.0], [0.5, 3.0]]]]])
+    var = lambda g: (1 - g) ** 2 * s * s + g * g
+    want = x.double() * s / var(sig[0]).sqrt()
+    for i in range(steps):
+        g = sig[i]
+        v = ((g - (1 - g) * s * s) / var(g)) * x.double()
+        x = step(sch, i, v.float(), x)
+    return ((x.double() - want).norm() / want.norm()).item()
+
+
+@pytest.mark.parametrize("which", ["product", "oracle"])
+def test_second_order_convergence_on_the_gaussian_flow(which):
+    """UniPC (bh2, solver_order 2, corrector on) is a second-order method: on the one problem whose exact flow is known in closed form the
+    end-point error must fall ~4x per doubling of the step count.  A first-order scheme (or wrong multistep coefficients, a mis-indexed
+    history, a corrector applied to the wrong sample) falls 2x - this pins both restatements against the published algorithm itself."""
+    def make(shift, steps):
+        if which == "product":
+            a = UniPCMultistepScheduler(flow_shift=shift)
+            a.set_timesteps(steps)
+            return a, (lambda sch, i, v, x: sch.step(v, sch.timesteps[i], x)[0])
+        o = OracleUniPC(flow_shift=shift)
+        o.set_timesteps(steps)
+        return o, (lambda sch, i, v, x: sch.step(v, x))
+    errs = [_gaussian_flow_error(make, n) for n in (10, 20, 40, 80)]
+    assert errs[0] < 5e-2 and errs[-1] < 1e-3, errs            # measured 1.6e-2, 5.9e-3, 1.4e-3, 3.1e-4 (both restatements)
+    assert errs[0] / errs[1] > 2.0, errs                       # 10 steps are not yet asymptotic (the first step leaves sigma = 0.999): 2.7
+    assert errs[1] / errs[2] > 3.5 and errs[2] / errs[3] > 3.5, errs   # measured 4.3 and 4.5: second order (a first-order scheme gives 2)
