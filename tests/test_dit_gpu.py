@@ -74,6 +74,34 @@ def test_batch2_equals_two_batch1_calls(tiny):
     assert torch.equal(both[0], a[0]) and torch.equal(both[1], b[0])
 
 
+def test_forward_is_invariant_to_the_order_of_the_real_text_tokens(tiny):
+    """The cross-attention has no positions on the text side (tests/test_oracle_dit.py shows it for the oracle): permuting the REAL rows of a
+    zero-padded prompt must leave the HIP forward unchanged up to summation order - through the merged padding key, the cached V.Wo^T
+    operands and the probabilities kernel, whose key order it changes."""
+    ocfg, sd, model = tiny
+    g = torch.Generator().manual_seed(16)
+    lat = torch.randn(2, 16, 2, 16, 16, generator=g).to(torch.bfloat16).cuda()
+    text = torch.randn(2, 64, ocfg.text_dim, generator=g) * 0.5
+    text[0, 23:] = 0
+    text[1, 41:] = 0
+    t = torch.tensor([650, 650]).cuda()
+    y = model(lat, t, text.cuda())[0].float().clone()
+    perm = text.clone()
+    perm[0, :23] = text[0, torch.randperm(23, generator=g)]
+    perm[1, :41] = text[1, torch.randperm(41, generator=g)]
+    y2 = model(lat, t, perm.cuda())[0].float().clone()
+    r = _rel(y2, y)
+    assert r < 2e-3, r            # bf16 rounding of differently ordered sums; a position-dependent bug is O(1)
+    # (moving a token into the padding region is ALSO a permutation of the same multiset of keys - interior zero rows stay ordinary keys, the
+    # trailing run is merged - and must not change the output either; changing a token's VALUE must)
+    moved = text.clone()
+    moved[0, 0], moved[0, 30] = 0, text[0, 0]
+    assert _rel(model(lat, t, moved.cuda())[0].float(), y) < 2e-3
+    changed = text.clone()
+    changed[0, 5] = -text[0, 5]
+    assert _rel(model(lat, t, changed.cuda())[0].float(), y) > 1e-4
+
+
 def test_denoise_loop_matches_oracle_loop(tiny):
     """4-step CFG denoise: product pipeline (HIP DiT + host UniPC) vs oracle DiT (bf16 points) + oracle UniPC."""
     from oracle.unipc import OracleUniPC
