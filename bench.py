@@ -133,9 +133,26 @@ def coop_requested(a, world):
     return a.parallel == "scene" and world > 1
 
 
+def parse_rocm_smi(text):
+    """(sclk MHz, socket power W) from `rocm-smi --showclocks --showpower --json` (first card of the output), or None."""
+    import re
+    try:
+        card = next(iter(json.loads(text).values()))
+    except Exception:
+        return None
+    mhz = [int(re.search(r"(\d+)\s*Mhz", str(v), re.I).group(1)) for k, v in card.items() if "sclk" in k.lower() and re.search(r"\d+\s*Mhz", str(v), re.I)]
+    watts = []
+    for k, v in card.items():
+        if "power (w)" in k.lower():
+            try:
+                watts.append(float(v))
+            except (TypeError, ValueError):
+                pass
+    return (mhz[0], watts[0]) if mhz and watts else None
+
+
 def sustained_clock(load, device_index, samples=4):
     """Median shader clock / socket power rocm-smi reports while `load()` (one untimed scene) is repeated on the GPU."""
-    import re
     import subprocess
     import threading
     got = []
@@ -145,11 +162,9 @@ def sustained_clock(load, device_index, samples=4):
         for _ in range(samples):
             try:
                 r = subprocess.run(["rocm-smi", "-d", str(device_index), "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20)
-                card = next(iter(json.loads(r.stdout).values()))
-                mhz = [int(re.search(r"(\d+)\s*Mhz", str(v), re.I).group(1)) for k, v in card.items() if "sclk" in k.lower() and re.search(r"\d+\s*Mhz", str(v), re.I)]
-                watts = [float(v) for k, v in card.items() if "power (w)" in k.lower()]
-                if mhz and watts:
-                    got.append((mhz[0], watts[0]))
+                one = parse_rocm_smi(r.stdout)
+                if one:
+                    got.append(one)
             except Exception:
                 pass
 

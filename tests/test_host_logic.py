@@ -376,3 +376,20 @@ def test_oracle_digest_cache_roundtrip(tmp_path, monkeypatch):
     import pytest
     with pytest.raises(AssertionError):
         OC.oracle("unit", OC.checksum(x), comp)
+
+
+def test_bench_parses_the_rocm_smi_clock_and_power_sample():
+    """bench.py's untimed clock extra: shader clock and package power out of `rocm-smi --showclocks --showpower --json` as the MI355X boxes
+    print it; anything else (no GPU, other key names, an error text) gives None and the bench line carries null."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sample = ('{"card0": {"fclk clock speed:": "(1250Mhz)", "fclk clock level:": "0", "mclk clock speed:": "(2000Mhz)", "mclk clock level:": "0", '
+              '"sclk clock speed:": "(1977Mhz)", "sclk clock level:": "1", "socclk clock speed:": "(38Mhz)", '
+              '"Current Socket Graphics Package Power (W)": "1307.0"}}')
+    assert bench.parse_rocm_smi(sample) == (1977, 1307.0)
+    assert bench.parse_rocm_smi('{"card0": {"sclk clock level:": "S"}}') is None
+    assert bench.parse_rocm_smi("ERROR: no GPU") is None and bench.parse_rocm_smi("") is None
+    assert bench.parse_rocm_smi('{"card0": {"sclk clock speed:": "(95Mhz)", "Average Graphics Package Power (W)": "N/A"}}') is None
