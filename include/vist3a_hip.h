@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 18) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 19) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -150,6 +150,40 @@ typedef struct {
 } v3a_conv_args;
 int v3a_conv_bf16(const v3a_conv_args* args, void* stream);
 long v3a_conv_halo_tiles(const v3a_conv_args* args);   /* workgroups the halo kernel would launch; 0 = layer not of its form */
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32-EQUIVALENT convolution on the bf16 matrix pipe ("split bf16"), for the layers the reference runs with autocast OFF:
+ *   /root/reference/models/anysplat_stitched.py:335 (`with torch.amp.autocast("cuda", enabled=False)` around camera / depth / Gaussian heads)
+ *   /root/reference/third_party_model/anysplat/src/model/encoder/vggt/heads/dpt_head.py:185-309 (DPT trunk + output convs, fp32 weights:
+ *   utils/utils_for_thirdparty.py:53-69), .../encoder/heads/vggt_dpt_gs_head.py:122-176.
+ * An fp32 tensor t travels as an unevaluated PAIR of bf16 planes of its shape, t = hi + lo with hi = bf16(t), lo = bf16(t - hi)
+ * (|t - hi - lo| <= 2^-17 |t|).  With x = xh + xl and w = wh + wl the convolution is the sum of three bf16 products with fp32
+ * accumulation,  xl.wh + xh.wl + xh.wh  (the dropped xl.wl term is <= 2^-16 relative), laid out ALONG K of one implicit GEMM:
+ *   w[Cout][Kpad]: three consecutive copies of the tap-major K range of v3a_conv_args, holding (wh | wl | wh);
+ *   ktab: the chunk table of the three ranges, bit 28 set where the chunk reads the LO plane of x (first range), clear for the hi plane.
+ * Everything that follows the accumulation stays in fp32: v = act(acc + bias) (act NONE or RELU) + residual + residual2 ; [RELU_OUT] ;
+ * stored as f32 (V3A_GEMM_OUT_F32) or split into the (y, y_lo) planes.  residual: f32 [.., ldr] with V3A_GEMM_RES_F32 (a table, see
+ * res_row_mod) else a pair (c.residual, residual_lo); residual2: a pair.  c.scale, c.w_halo must be NULL; tile as in v3a_conv_bf16
+ * (the halo kernel has no split form).  Geometry fields (T..pW, ups2, replicate, ldy, out_row_*) as in v3a_conv_args; both planes of a pair
+ * share strides.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  v3a_conv_args c;            /* x, y, residual, residual2 = the HI planes */
+  const void* x_lo; void* y_lo; const void* residual_lo; const void* residual2_lo;
+} v3a_conv_split_args;
+int v3a_conv_split(const v3a_conv_split_args* args, void* stream);
+/* Row / pixel passes between the split convolutions (csrc/pair.hip), fp32 arithmetic, pair in / pair out:
+ *   v3a_split_f32        x f32 [n] (n % 8 == 0) -> (hi, lo)
+ *   v3a_layernorm_pair   F.layer_norm of f32 rows x[row(m)][0..d) (row(m) = m + (m / in_row_group) * in_row_skip + in_row_off when
+ *                        in_row_group > 0), affine weight / bias f32 [d] or NULL -> pair rows [M][ldy]; d % 8 == 0, d <= 2048
+ *                        (dpt_head.py:213-216 `self.norm` on the tapped tokens)
+ *   v3a_bilinear_cl_pair v3a_bilinear_cl on pairs: x [T][h][w][C] -> y [T][H][W][C], + optional pair `add` [T][H][W][C], + optional f32
+ *                        `table` [H*W][C] broadcast over T (dpt_head.py:291-309,460-466, vggt_dpt_gs_head.py:166) */
+int v3a_split_f32(const float* x, void* hi, void* lo, long n, void* stream);
+int v3a_layernorm_pair(const float* x, void* y_hi, void* y_lo, const float* weight, const float* bias, int M, int d, int ldx, int ldy,
+                       float eps, int in_row_group, int in_row_skip, int in_row_off, void* stream);
+int v3a_bilinear_cl_pair(const void* x_hi, const void* x_lo, void* y_hi, void* y_lo, const void* add_hi, const void* add_lo,
+                         const float* table, int T, int h, int w, int H, int W, int C, int align_corners, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Flash attention forward (non-causal, no mask, no dropout), bf16 in/out, fp32 softmax.

@@ -40,6 +40,7 @@ struct TileCfg {
   static constexpr int PITCH = WTN * 2 + 8;
   static constexpr int EPI_BYTES = NW * 32 * PITCH;   // the epilogue parks one 32-row group per wave at a time
   static constexpr int LDS_BYTES = (NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
+  static constexpr int EPI_F32_BYTES = NW * 32 * (WTN * 4 + 16);   // split-bf16 convolution: the same park in fp32
   static constexpr bool CONV_OK = (BM / RPI) % NW == 0 && NINS % NW == 0;
   static_assert(BK == 32 || BK == 64, "BK");
   static_assert(NS >= 2, "ring depth");
@@ -53,7 +54,10 @@ struct TileCfg {
 //          are issued, and the slab t+1 registers written to LDS, BETWEEN the MFMA groups of slab t.  An LDS-DMA instruction
 //          occupies its wave for ~100+ cycles at issue and every wave of the workgroup issues them at the same point, so
 //          DMA staging leaves the matrix pipe idle for ~40 % of each slab (measured: 1468 TF without refill vs 830 with).
-template <int BM, int BN, int WM, int WN, int BK, int NS, bool CONV, int STG>
+// CONV = 0: plain GEMM; 1: implicit-GEMM convolution (A gathered through the K-chunk table); 2: the same with fp32-equivalent
+//        arithmetic (v3a_conv_split): A is a (hi, lo) bf16 pair of planes, bit 28 of a table entry selects the plane, the weight
+//        matrix carries the three partial products side by side along K, and the epilogue stays in fp32 (gemm_epilogue_f32).
+template <int BM, int BN, int WM, int WN, int BK, int NS, int CONV, int STG>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel(const GemmP pin) {
   GemmP p = pin;
   if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; if (p.res) p.res += blockIdx.y * p.rz; if (p.rowsq) p.rowsq += (size_t)blockIdx.y * p.M * (p.N / 32); }
@@ -62,6 +66,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel
   constexpr int WTM = T::WTM, WTN = T::WTN, PITCH = T::PITCH;
   constexpr int RB = T::RB, CPR = T::CPR, RPI = T::RPI, NINS = T::NINS, KSTEPS = T::KSTEPS;
   static_assert(!CONV || T::CONV_OK, "conv needs an even A/B instruction split");
+  static_assert(CONV != 2 || T::EPI_F32_BYTES <= T::LDS_BYTES, "fp32 park must fit the tile ring");
   static_assert(STG == 0 || NS == 2, "register staging uses two LDS buffers");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel
             ok = ok && tt >= 0 && tt < p.cT && hh >= 0 && hh < eH && ww >= 0 && ww < eW;
           }
           if (p.ups) { hh >>= 1; ww >>= 1; }
-          const char* src = p.A + (((size_t)(tt * p.cH + hh) * p.cW + ww) * p.cCin + (e & 0xffff)) * 2;
+          const char* src = ((CONV == 2 && (e & (1 << 28))) ? p.A_lo : p.A) + (((size_t)(tt * p.cH + hh) * p.cW + ww) * p.cCin + (e & 0xffff)) * 2;
           glds16(ok ? src : (const char*)&g_zero16, smem + s * STAGE + g * 1024);
           continue;
         }
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel
             ok = ok && tt >= 0 && tt < p.cT && hh >= 0 && hh < eH && ww >= 0 && ww < eW;
           }
           if (p.ups) { hh >>= 1; ww >>= 1; }
-          const char* src = p.A + (((size_t)(tt * p.cH + hh) * p.cW + ww) * p.cCin + (e & 0xffff)) * 2;
+          const char* src = ((CONV == 2 && (e & (1 << 28))) ? p.A_lo : p.A) + (((size_t)(tt * p.cH + hh) * p.cW + ww) * p.cCin + (e & 0xffff)) * 2;
           rg[j] = *(const u32x4*)(ok ? src : (const char*)&g_zero16);
           continue;
         }
@@ -298,7 +303,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN + 3) / 4) void gemm_nt_kernel
 
   gemm_add_bias<MT, NTL>(p, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
   if constexpr (!CONV) gemm_row_sumsq<MT, NTL>(p, acc, lane, m0 + wm * WTM, n0 + wn * WTN);
-  gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8)>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+  if constexpr (CONV == 2) gemm_epilogue_f32<MT, NTL>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
+  else gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8)>(p, acc, smem, wave, lane, m0 + wm * WTM, n0 + wn * WTN);
 }
 
 // =====================================================================================================================
@@ -635,21 +641,26 @@ typedef void (*gemm_fn)(const GemmP);
 struct TileEntry {
   const char* name;
   int BM, BN, nthr, lds;
-  gemm_fn fn, conv_fn;
+  gemm_fn fn, conv_fn, split_fn;
 };
 template <int BM, int BN, int WM, int WN, int BK, int NS, int STG>
 constexpr gemm_fn conv_kernel_or_null() {
-  if constexpr (TileCfg<BM, BN, WM, WN, BK, NS>::CONV_OK) return (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, true, STG>;
+  if constexpr (TileCfg<BM, BN, WM, WN, BK, NS>::CONV_OK) return (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, 1, STG>;
+  else return nullptr;
+}
+template <int BM, int BN, int WM, int WN, int BK, int NS, int STG>
+constexpr gemm_fn split_kernel_or_null() {
+  if constexpr (TileCfg<BM, BN, WM, WN, BK, NS>::CONV_OK) return (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, 2, STG>;
   else return nullptr;
 }
 #define TILE_ENTRY_S(BM, BN, WM, WN, BK, NS, STG)                                                   \
   { #BM "x" #BN "_w" #WM "x" #WN "_k" #BK "s" #NS "_stg" #STG, BM, BN, TileCfg<BM, BN, WM, WN, BK, NS>::NTHR, \
-    TileCfg<BM, BN, WM, WN, BK, NS>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, false, STG>, \
-    conv_kernel_or_null<BM, BN, WM, WN, BK, NS, STG>() }
+    TileCfg<BM, BN, WM, WN, BK, NS>::LDS_BYTES, (gemm_fn)gemm_nt_kernel<BM, BN, WM, WN, BK, NS, 0, STG>, \
+    conv_kernel_or_null<BM, BN, WM, WN, BK, NS, STG>(), split_kernel_or_null<BM, BN, WM, WN, BK, NS, STG>() }
 #define TILE_ENTRY(BM, BN, WM, WN, BK, NS) TILE_ENTRY_S(BM, BN, WM, WN, BK, NS, 0)
 #define PP_ENTRY(NP, RA, LEAD)                                                                      \
   { "pp_np" #NP "_ra" #RA "_l" #LEAD, (RA) ? 256 : 64 * NP, (RA) ? 64 * NP : 256, 512, PPCfg<NP>::LDS_BYTES, \
-    (gemm_fn)gemm_pp_kernel<NP, RA, LEAD>, nullptr }
+    (gemm_fn)gemm_pp_kernel<NP, RA, LEAD>, nullptr, nullptr }
 
 const TileEntry kTiles[] = {
     TILE_ENTRY(256, 192, 4, 2, 64, 2),  // 0: lockstep main loop (also the implicit-GEMM convolution): N % 192 == 0 shapes
@@ -674,12 +685,12 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 // e4m3 forms of the ping-pong tiles (K tile = 128 elements: the same bytes per row, twice the matrix rate)
 #define PP8_ENTRY(NP, RA, LEAD)                                                                     \
   { "pp8_np" #NP "_ra" #RA "_l" #LEAD, (RA) ? 256 : 64 * NP, (RA) ? 64 * NP : 256, 512, PPCfg<NP>::LDS_BYTES, \
-    (gemm_fn)gemm_pp_kernel<NP, RA, LEAD, true>, nullptr }
+    (gemm_fn)gemm_pp_kernel<NP, RA, LEAD, true>, nullptr, nullptr }
 // (the 256x256 form spills in its epilogue and measured slower on every Wan-14B / 1.3B shape: not instantiated)
 const TileEntry kTilesF8[] = {PP8_ENTRY(3, true, 5), PP8_ENTRY(3, false, 5)};
 constexpr int kNumTilesF8 = 2;
 int g_attr_lds_f8[kNumTilesF8] = {};
-int g_attr_lds[kNumTiles][2] = {};
+int g_attr_lds[kNumTiles][3] = {};
 
 // tiles the heuristic may choose from (the rest are explicit / tuning variants); the ping-pong tiles have no conv form
 constexpr int kAutoList[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
@@ -714,10 +725,10 @@ int pick_tile(int M, int N, bool conv = false, int mult = 1, int act = 0) {
   return bi;
 }
 
-int launch(const GemmP& p, int ti, bool conv, void* stream, int nz = 1) {
-  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N, conv, nz, p.act);
+int launch(const GemmP& p, int ti, int conv, void* stream, int nz = 1) {   // conv: 0 GEMM, 1 convolution, 2 split-bf16 convolution
+  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N, conv != 0, nz, p.act);
   const TileEntry& e = kTiles[ti];
-  const gemm_fn fn = conv ? e.conv_fn : e.fn;
+  const gemm_fn fn = conv == 2 ? e.split_fn : conv ? e.conv_fn : e.fn;
   if (!fn) return V3A_ERR_ARG;  // this tile shape has no conv instantiation
   const int lds = e.lds + (conv ? p.K / 8 * 4 : 0);
   if (lds > 160 * 1024) return V3A_ERR_SHAPE;
@@ -866,7 +877,7 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
     p.az = a->a_batch_stride * 2; p.bz = a->b_batch_stride * 2;
     p.cz = a->c_batch_stride * ((a->flags & V3A_GEMM_OUT_F32) ? 4 : 2);
     p.rz = a->res_batch_stride * ((a->flags & V3A_GEMM_RES_F32) ? 4 : 2);
-    return launch(p, a->tile, false, stream, a->batch);
+    return launch(p, a->tile, 0, stream, a->batch);
   }
   if (a->split_k > 1) {   // S equally long K slices side by side (blockIdx.y), bf16 partials, then the epilogue in a second launch
     const int S = a->split_k;
@@ -875,7 +886,7 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
     q.A = p.A; q.B = p.B; q.C = (char*)a->workspace;
     q.M = p.M; q.N = p.N; q.K = p.K / S; q.lda = p.lda; q.ldb = p.ldb; q.ldc = p.N; q.rpb = 1;
     q.az = (long)q.K * 2; q.bz = (long)q.K * 2; q.cz = (long)p.M * p.N * 2;
-    const int rc = launch(q, a->tile, false, stream, S);
+    const int rc = launch(q, a->tile, 0, stream, S);
     if (rc != V3A_OK) return rc;
     SplitFinP f = {(const char*)a->workspace, p.C, p.bias, p.res, p.scale, p.res2, p.M, p.N, S, p.ldc, p.ldr, p.ldr2, p.rpb, p.sstride,
                    p.act, p.flags, p.res_mod, p.orow_group, p.orow_skip, p.orow_off};
@@ -883,7 +894,7 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
     hipLaunchKernelGGL(gemm_splitk_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f);
     return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
   }
-  return launch(p, a->tile, false, stream);
+  return launch(p, a->tile, 0, stream);
 }
 
 extern "C" size_t v3a_gemm_split_workspace_bytes(int M, int N, int split_k) {
@@ -938,5 +949,25 @@ extern "C" int v3a_conv_bf16(const v3a_conv_args* a, void* stream) {
     const int rc = v3a_conv_halo_launch(a, stream);
     if (rc != V3A_ERR_SHAPE || a->tile == -2) return rc;
   }
-  return launch(p, a->tile < 0 ? -1 : a->tile, true, stream);
+  return launch(p, a->tile < 0 ? -1 : a->tile, 1, stream);
+}
+
+// fp32-equivalent convolution on the bf16 matrix pipe (include/vist3a_hip.h: v3a_conv_split): the implicit-GEMM main loop over the
+// K-concatenated partial products, fp32 epilogue.
+extern "C" int v3a_conv_split(const v3a_conv_split_args* s, void* stream) {
+  if (!s) return V3A_ERR_ARG;
+  const v3a_conv_args* a = &s->c;
+  if (!a->x || !s->x_lo || !a->w || !a->y || !a->ktab) return V3A_ERR_ARG;
+  if (a->T <= 0 || a->H <= 0 || a->W <= 0 || a->Cin <= 0 || a->oT <= 0 || a->oH <= 0 || a->oW <= 0 || a->Cout <= 0) return V3A_ERR_SHAPE;
+  if (a->Cin % 8 || a->Cout % 8 || a->Kpad % 64 || a->ldy % 8 || a->Kpad / 8 > 4096) return V3A_ERR_SHAPE;
+  if ((long)a->oT * a->oH * a->oW > 0x7fffffffL) return V3A_ERR_SHAPE;
+  if (a->flags & ~(V3A_GEMM_RES_F32 | V3A_GEMM_OUT_F32 | V3A_GEMM_RELU_OUT)) return V3A_ERR_ARG;
+  if (a->act != V3A_ACT_NONE && a->act != V3A_ACT_RELU) return V3A_ERR_ARG;
+  if (a->scale || a->w_halo) return V3A_ERR_ARG;
+  if (!(a->flags & V3A_GEMM_OUT_F32) && !s->y_lo) return V3A_ERR_ARG;
+  if (a->residual && ((a->ldr % 8) || (!(a->flags & V3A_GEMM_RES_F32) && !s->residual_lo))) return V3A_ERR_ARG;
+  if (a->residual2 && ((a->ldr2 % 8) || !s->residual2_lo)) return V3A_ERR_ARG;
+  GemmP p = conv_gemm_params(a);
+  p.A_lo = (const char*)s->x_lo; p.C_lo = (char*)s->y_lo; p.res_lo = (const char*)s->residual_lo; p.res2_lo = (const char*)s->residual2_lo;
+  return launch(p, a->tile < 0 ? -1 : a->tile, 2, stream);
 }

@@ -34,6 +34,8 @@ struct GemmP {
   // blockIdx.y = z selects one of several equally shaped problems (split-K slices, batched operands): byte offsets of A, B, C, res per z
   long az, bz, cz, rz;
   float* rowsq;           // optional by-product: sum of squares of every (row, 32-column block) of bf16(acc + bias), [M][N / 32] f32
+  // split-bf16 convolution (CONV == 2 instantiations only): the lo planes of the (hi, lo) bf16 pairs; hi planes are A / C / res / res2
+  const char* A_lo; char* C_lo; const char* res_lo; const char* res2_lo;
 };
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -328,6 +330,109 @@ __device__ __forceinline__ void gemm_row_sumsq(const GemmP& p, const f32x16 (&ac
       const int m = mw0 + i * 32 + l31, n = nw + j * 32;
       if (hi == 0 && m < p.M && n < p.N) p.rowsq[(size_t)m * nb + (n >> 5)] = s;
     }
+}
+
+// x -> (hi, lo) with hi = bf16(x) and lo = bf16(x - hi): x = hi + lo to 2^-17 relative (16 significand bits + the sign of lo).
+__device__ __forceinline__ void split_bf16x8(const float* v, u32x4& hi, u32x4& lo) {
+  hi = pack_bf16x8(v);
+  float h[8], r[8];
+  unpack_bf16x8(hi, h);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = v[e] - h[e];
+  lo = pack_bf16x8(r);
+}
+__device__ __forceinline__ void add_pair8(const u32x4 hi, const u32x4 lo, float* v) {
+  float a[8], b[8];
+  unpack_bf16x8(hi, a);
+  unpack_bf16x8(lo, b);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] += a[e] + b[e];
+}
+
+// Epilogue of the split-bf16 convolution (v3a_conv_split): nothing is rounded to bf16 on the way.  The wave parks one 32-row group of
+// fp32 accumulators (bias added, ReLU applied) in its private LDS region, re-reads whole rows and finishes 8 columns per lane:
+//   v = act(acc + bias) + residual (f32 table, or a (hi, lo) pair) + residual2 (pair) ; [ReLU] ; store f32, or split into the (hi, lo) planes.
+template <int MT, int NTL>
+__device__ __forceinline__ void gemm_epilogue_f32(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane, int mw0, int nw) {
+  constexpr int WTN = NTL * 32, PITCH = WTN * 4 + 16;
+  constexpr int CH = WTN / 8, ITERS = 32 * CH / 64;
+  static_assert((32 * CH) % 64 == 0, "epilogue chunking");
+  const int hi = lane >> 5, l31 = lane & 31;
+  char* reg = smem + wave * (32 * PITCH);
+  const int flags = p.flags;
+  const bool relu_in = p.act == V3A_ACT_RELU, res_f32 = (flags & V3A_GEMM_RES_F32) != 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int mw = mw0 + i * 32;
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = relu_in ? fmaxf(acc[i][j][g * 4 + e], 0.f) : acc[i][j][g * 4 + e];
+        *(f32x4*)(reg + l31 * PITCH + (j * 32 + g * 8 + hi * 4) * 4) = v;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = it * 64 + lane;
+      const int ml = idx / CH, ch = idx % CH;
+      const int m = mw + ml, n = nw + ch * 8;
+      const bool inside = m < p.M && n < p.N;
+      const int mc = min(m, p.M - 1), nc = min(n, p.N - 8);   // clamped addresses: loads stay branch-free, the store is predicated
+      u32x4 r0 = {}, r1 = {}, q0 = {}, q1 = {};
+      if (p.res) {
+        const int mr = p.res_mod > 0 ? mc % p.res_mod : mc;
+        if (res_f32) {
+          const float* rp = (const float*)p.res + (size_t)mr * p.ldr + nc;
+          r0 = *(const u32x4*)rp; r1 = *(const u32x4*)(rp + 4);
+        } else {
+          r0 = *(const u32x4*)(p.res + ((size_t)mr * p.ldr + nc) * 2);
+          r1 = *(const u32x4*)(p.res_lo + ((size_t)mr * p.ldr + nc) * 2);
+        }
+      }
+      if (p.res2) {
+        q0 = *(const u32x4*)(p.res2 + ((size_t)mc * p.ldr2 + nc) * 2);
+        q1 = *(const u32x4*)(p.res2_lo + ((size_t)mc * p.ldr2 + nc) * 2);
+      }
+      const f32x4 a = *(const f32x4*)(reg + ml * PITCH + ch * 32), b = *(const f32x4*)(reg + ml * PITCH + ch * 32 + 16);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+      if (p.res) {
+        if (res_f32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += __uint_as_float(r0[e]); v[4 + e] += __uint_as_float(r1[e]); }
+        } else {
+          add_pair8(r0, r1, v);
+        }
+      }
+      if (p.res2) add_pair8(q0, q1, v);
+      if (flags & V3A_GEMM_RELU_OUT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      const size_t mo = p.orow_group > 0 ? (size_t)m + (size_t)(m / p.orow_group) * p.orow_skip + p.orow_off : (size_t)m;
+      if (flags & V3A_GEMM_OUT_F32) {
+        float* cp = (float*)p.C + mo * p.ldc + n;
+        f32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o0[e] = v[e]; o1[e] = v[4 + e]; }
+        if (inside) { *(f32x4*)cp = o0; *(f32x4*)(cp + 4) = o1; }
+      } else {
+        u32x4 oh, ol;
+        split_bf16x8(v, oh, ol);
+        if (inside) {
+          *(u32x4*)(p.C + (mo * p.ldc + n) * 2) = oh;
+          *(u32x4*)(p.C_lo + (mo * p.ldc + n) * 2) = ol;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // the implicit-GEMM view of a convolution (M = output pixels, N = Cout, K = Kpad) + the epilogue operands

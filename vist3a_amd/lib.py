@@ -55,6 +55,10 @@ class ConvArgs(C.Structure):
     ]
 
 
+class ConvSplitArgs(C.Structure):
+    _fields_ = [("c", ConvArgs), ("x_lo", C.c_void_p), ("y_lo", C.c_void_p), ("residual_lo", C.c_void_p), ("residual2_lo", C.c_void_p)]
+
+
 class GemmSkinnyArgs(C.Structure):
     _fields_ = [
         ("X", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
@@ -189,6 +193,10 @@ SYMBOLS = {
     "v3a_gemm_tile_name": (C.c_char_p, [C.c_int]),
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_conv_halo_tiles": (C.c_long, [C.POINTER(ConvArgs)]),
+    "v3a_conv_split": (C.c_int, [C.POINTER(ConvSplitArgs), C.c_void_p]),
+    "v3a_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "v3a_layernorm_pair": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float] + [C.c_int] * 3 + [C.c_void_p]),
+    "v3a_bilinear_cl_pair": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p]),
     "v3a_attention_fwd_bf16": (C.c_int, [C.POINTER(AttnArgs), C.c_void_p]),
     "v3a_xattn_probs_bf16": (C.c_int, [C.POINTER(XattnProbsArgs), C.c_void_p]),
     "v3a_attention_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -227,7 +235,7 @@ SYMBOLS = {
 }
 
 _lib = None
-EXPECTED_ABI = 18   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
+EXPECTED_ABI = 19   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
 
 
 class HipLibraryError(RuntimeError):

@@ -81,11 +81,12 @@ class StitchVAE3D(torch.nn.Module):
         S = lat_cl.shape[0]
         if image_cl is None:
             H, W = feedforward_image.shape[-2:]
-            image_cl = torch.zeros(S, H, W, 8, device=self.device, dtype=torch.bfloat16)
-            image_cl[..., :3] = feedforward_image[0].to(self.device).permute(1, 2, 3, 0)
+            image_cl = torch.zeros(S, H, W, 8, device=self.device, dtype=torch.float32)
+            image_cl[..., :3] = feedforward_image[0].to(self.device).float().permute(1, 2, 3, 0)
         else:
             H, W = image_cl.shape[1:3]
-        img01 = (image_cl + 1) / 2  # context_image = (context_image + 1) / 2  (anysplat_stitched.py:175)
+        # context_image = (context_image + 1) / 2 in fp32 (anysplat_stitched.py:174-175), whatever dtype the image arrived in
+        img01 = (image_cl.float() + 1) / 2
         img01[..., 3:] = 0
         x, g = eng.token_workspace(S, H, W)
         hw, Pp, nsp = g["hw"], g["Pp"], g["nsp"]

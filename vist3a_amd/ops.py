@@ -336,6 +336,163 @@ def conv(
     return out
 
 
+# ------------------------------------------------------------------------------------------------ fp32-equivalent ("split bf16") path
+# A PAIR is a contiguous bf16 tensor [2, ...]: plane 0 = hi = bf16(x), plane 1 = lo = bf16(x - hi); x = hi + lo (include/vist3a_hip.h,
+# v3a_conv_split).  The layers the reference runs with autocast off (anysplat_stitched.py:335) carry their activations in this form.
+
+def pair_value(p: torch.Tensor) -> torch.Tensor:
+    """the fp32 value of a pair (tests / glue; the kernels never materialise it)"""
+    return p[0].float() + p[1].float()
+
+
+def split_f32(x: torch.Tensor) -> torch.Tensor:
+    """contiguous f32 [...] (numel % 8 == 0) -> pair [2, ...]"""
+    if x.dtype != f32 or not x.is_contiguous() or not x.is_cuda or x.numel() % 8:
+        raise ValueError("x must be a contiguous device f32 tensor with numel % 8 == 0")
+    out = torch.empty((2,) + tuple(x.shape), device=x.device, dtype=bf16)
+    L.check(L.load().v3a_split_f32(_ptr(x), _ptr(out[0]), _ptr(out[1]), x.numel(), _stream()), "v3a_split_f32")
+    return out
+
+
+def layernorm_pair(x: torch.Tensor, *, weight: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, eps: float = 1e-5,
+                   M: Optional[int] = None, in_rows: tuple = (0, 0, 0)) -> torch.Tensor:
+    """F.layer_norm of f32 rows -> pair [2, M, d]; in_rows as in `layernorm`."""
+    _chk2d(x, "x", (f32,))
+    d = x.shape[1]
+    if M is None:
+        M = x.shape[0]
+    for t in (weight, bias):
+        if t is not None and (t.dtype != f32 or not t.is_contiguous() or t.numel() != d):
+            raise ValueError("affine weight/bias must be contiguous f32 [d]")
+    out = torch.empty((2, M, d), device=x.device, dtype=bf16)
+    L.check(L.load().v3a_layernorm_pair(_ptr(x), _ptr(out[0]), _ptr(out[1]), _ptr(weight), _ptr(bias), M, d, x.stride(0), d, eps,
+                                        *in_rows, _stream()), "v3a_layernorm_pair")
+    return out
+
+
+def bilinear_cl_pair(x: torch.Tensor, size, *, align_corners: bool, add: Optional[torch.Tensor] = None,
+                     table: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pair [2,T,h,w,C] -> pair [2,T,H,W,C] (+ pair `add` of the output's shape, + f32 `table` [H*W, C])."""
+    if x.dtype != bf16 or not x.is_contiguous() or x.dim() != 5 or x.shape[0] != 2:
+        raise ValueError("x must be a contiguous bf16 pair [2,T,h,w,C]")
+    _, T, h, w, Cc = x.shape
+    H, W = size
+    out = torch.empty((2, T, H, W, Cc), device=x.device, dtype=bf16)
+    if add is not None and (add.dtype != bf16 or not add.is_contiguous() or tuple(add.shape) != tuple(out.shape)):
+        raise ValueError("add must be a contiguous pair with the output's shape")
+    if table is not None and (table.dtype != f32 or not table.is_contiguous() or table.numel() != H * W * Cc):
+        raise ValueError("table must be contiguous f32 [H*W, C]")
+    L.check(L.load().v3a_bilinear_cl_pair(_ptr(x[0]), _ptr(x[1]), _ptr(out[0]), _ptr(out[1]), _ptr(add[0]) if add is not None else None,
+                                          _ptr(add[1]) if add is not None else None, _ptr(table), T, h, w, H, W, Cc, int(align_corners),
+                                          _stream()), "v3a_bilinear_cl_pair")
+    return out
+
+
+class ConvWeightSplit:
+    """An fp32 convolution weight packed for v3a_conv_split: w = wh + wl (bf16 pair), matrix [CoutP][Kpad] = (wh | wl | wh) along K, each
+    range tap-major / channel-minor like ConvWeight; the chunk table reads x's LO plane for the first range (bit 28) and its HI plane for
+    the other two:  acc = xl.wh + xh.wl + xh.wh  (small terms first).  f32 bias."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device="cuda"):
+        w = weight.detach()
+        if w.dim() == 4:
+            w = w[:, :, None]
+        if w.dim() == 3:
+            w = w[:, :, None, None]
+        Cout, Cin, kT, kH, kW = w.shape
+        self.Cout, self.Cin, self.k = Cout, Cin, (kT, kH, kW)
+        self.CinP, self.CoutP = (Cin + 7) // 8 * 8, (Cout + 7) // 8 * 8
+        K = kT * kH * kW * self.CinP
+        self.Kpad = (3 * K + 63) // 64 * 64
+        wp = torch.zeros(self.CoutP, kT, kH, kW, self.CinP, dtype=f32)
+        wp[:Cout, :, :, :, :Cin] = w.float().permute(0, 2, 3, 4, 1).cpu()
+        wp = wp.reshape(self.CoutP, K)
+        wh = wp.to(bf16)
+        wl = (wp - wh.float()).to(bf16)
+        full = torch.zeros(self.CoutP, self.Kpad, dtype=bf16)
+        full[:, :K], full[:, K:2 * K], full[:, 2 * K:3 * K] = wh, wl, wh
+        self.w = full.to(device).contiguous()
+        tab = torch.zeros(self.Kpad // 8, dtype=torch.int64)
+        idx = torch.arange(K // 8)
+        tap, c8 = idx // (self.CinP // 8), idx % (self.CinP // 8)
+        dt, dh, dw = tap // (kH * kW), (tap // kW) % kH, tap % kW
+        e = (c8 * 8) | (dw << 16) | (dh << 20) | (dt << 24) | (1 << 31)
+        tab[: K // 8], tab[K // 8: 2 * K // 8], tab[2 * K // 8: 3 * K // 8] = e | (1 << 28), e, e
+        tab = torch.where(tab >= 2 ** 31, tab - 2 ** 32, tab)
+        self.ktab = tab.to(torch.int32).to(device).contiguous()
+        b = torch.zeros(self.CoutP, dtype=f32)
+        if bias is not None:
+            b[:Cout] = bias.detach().float().cpu()
+        self.bias = b.to(device)
+        self.has_bias = bias is not None
+
+
+def conv_split(
+    x: torch.Tensor, cw: ConvWeightSplit, *, out: Optional[torch.Tensor] = None, stride=(1, 1, 1), pad=(0, 0, 0), out_size=None,
+    act: int = L.ACT_NONE, residual: Optional[torch.Tensor] = None, out_f32: bool = False, tile: int = -1,
+    residual2: Optional[torch.Tensor] = None, res_row_mod: int = 0, relu_out: bool = False, out_rows: Optional[tuple] = None,
+) -> torch.Tensor:
+    """fp32-equivalent convolution (v3a_conv_split).  x: pair [2,T,H,W,CinP] -> pair [2,oT,oH,oW,CoutP] (or f32 [oT,oH,oW,CoutP] with
+    out_f32).  residual: an f32 tensor (table; res_row_mod as in `conv`) or a pair; residual2: a pair.  No bf16 rounding anywhere between
+    the accumulator and the store; geometry arguments as in `conv`."""
+    if x.dim() != 5 or x.shape[0] != 2 or not x.is_contiguous() or x.dtype != bf16 or not x.is_cuda:
+        raise ValueError("x must be a contiguous device bf16 pair [2,T,H,W,C]")
+    _, T, H, W, Cin = x.shape
+    if Cin != cw.CinP:
+        raise ValueError(f"x has {Cin} channels, packed weight expects {cw.CinP}")
+    kT, kH, kW = cw.k
+    if out_size is None:
+        if kT > 1 and pad[0] == kT - 1:
+            oT = (T + pad[0] - kT) // stride[0] + 1
+        else:
+            oT = (T + 2 * pad[0] - kT) // stride[0] + 1
+        oH = (H + 2 * pad[1] - kH) // stride[1] + 1
+        oW = (W + 2 * pad[2] - kW) // stride[2] + 1
+    else:
+        oT, oH, oW = out_size
+    if out is None:
+        if out_rows is not None:
+            raise ValueError("out_rows needs an explicit out tensor")
+        out = torch.empty((oT, oH, oW, cw.CoutP) if out_f32 else (2, oT, oH, oW, cw.CoutP), device=x.device, dtype=f32 if out_f32 else bf16)
+    if out_f32:
+        if out.dtype != f32:
+            raise ValueError("out must be f32")
+        o_hi, o_lo = out.view(-1, out.shape[-1]), None
+    else:
+        if out.dtype != bf16 or out.shape[0] != 2 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous bf16 pair")
+        o_hi, o_lo = out[0].view(-1, out.shape[-1]), out[1]
+    flags = (L.GEMM_RELU_OUT if relu_out else 0) | (L.GEMM_OUT_F32 if out_f32 else 0)
+    r_hi = r_lo = None
+    ldr = 0
+    if residual is not None:
+        if residual.dtype == f32:
+            flags |= L.GEMM_RES_F32
+            r_hi = residual.view(-1, residual.shape[-1])
+        else:
+            if residual.dtype != bf16 or residual.shape[0] != 2 or not residual.is_contiguous():
+                raise ValueError("residual must be f32 or a contiguous bf16 pair")
+            r_hi, r_lo = residual[0].view(-1, residual.shape[-1]), residual[1]
+        ldr = r_hi.stride(0)
+    q_hi = q_lo = None
+    if residual2 is not None:
+        if residual2.dtype != bf16 or residual2.shape[0] != 2 or not residual2.is_contiguous():
+            raise ValueError("residual2 must be a contiguous bf16 pair")
+        q_hi, q_lo = residual2[0].view(-1, residual2.shape[-1]), residual2[1]
+    cargs = L.ConvArgs(
+        _ptr(x[0]), _ptr(cw.w), _ptr(cw.ktab), _ptr(o_hi), _ptr(cw.bias if cw.has_bias else None), _ptr(r_hi), None,
+        T, H, W, Cin, oT, oH, oW, cw.CoutP, cw.Kpad,
+        stride[0], stride[1], stride[2], pad[0], pad[1], pad[2],
+        0, 0, o_hi.stride(0), ldr, act, flags, tile,
+        _ptr(q_hi), q_hi.stride(0) if q_hi is not None else 0, res_row_mod,
+        *(out_rows if out_rows is not None else (0, 0, 0)),
+        None, 0,
+    )
+    args = L.ConvSplitArgs(cargs, _ptr(x[1]), _ptr(o_lo), _ptr(r_lo), _ptr(q_lo))
+    L.check(L.load().v3a_conv_split(C.byref(args), _stream()), "v3a_conv_split")
+    return out
+
+
 _attn_ws = {}   # per (device, thread) workspace of the key-split attention: stream-ordered reuse within a thread; virtual ranks
                 # (seqpar.ThreadWorld: threads sharing one stream) must not share it - their main / merge launches interleave
 

@@ -33,12 +33,17 @@ SD = Dict[str, torch.Tensor]
 class ReconCfg:
     def __init__(self, C=1024, heads=16, n_dino=22, depth=24, cam_heads=16, cam_trunk=4, features=256,
                  oc=(256, 512, 1024, 1024), patch=14, voxel_size=0.002, voxelize=True, sh_degree=4,
-                 taps=(4, 11, 17, 23), opacity_exponent=1.0, render_conf=False, conf_threshold=0.1):
+                 taps=(4, 11, 17, 23), opacity_exponent=1.0, render_conf=False, conf_threshold=0.1, dpt_precision="f32"):
         self.C, self.heads, self.n_dino, self.depth = C, heads, n_dino, depth
         self.cam_heads, self.cam_trunk, self.features, self.oc = cam_heads, cam_trunk, features, list(oc)
         self.patch, self.voxel_size, self.voxelize, self.sh_degree = patch, voxel_size, voxelize, sh_degree
         self.taps, self.opacity_exponent = tuple(taps), opacity_exponent
         self.render_conf, self.conf_threshold = render_conf, conf_threshold   # voxelize=False branch only (anysplat_stitched.py:381-387)
+        # "f32": the DPT heads in fp32-equivalent split-bf16 arithmetic - the reference's precision (autocast off, anysplat_stitched.py:335);
+        # "bf16": plain bf16 MFMA convolutions with bf16 activations (faster; a documented deviation, opt-in only)
+        if dpt_precision not in ("f32", "bf16"):
+            raise ValueError("dpt_precision must be 'f32' or 'bf16'")
+        self.dpt_precision = dpt_precision
 
 
 def uv_pos_embed(C: int, ph: int, pw: int, W: int, H: int, ratio: float = 0.1) -> torch.Tensor:
@@ -113,8 +118,10 @@ class _BlockF32:
 
 
 class _DPT:
-    def __init__(self, sd: SD, p: str, dev, gs: bool):
-        cw = lambda n, bias=True: ops.ConvWeight(sd[p + n + ".weight"], sd.get(p + n + ".bias") if bias else None, device=dev)
+    def __init__(self, sd: SD, p: str, dev, gs: bool, split: bool):
+        CW = ops.ConvWeightSplit if split else ops.ConvWeight
+        self.split = split
+        cw = lambda n, bias=True: CW(sd[p + n + ".weight"], sd.get(p + n + ".bias") if bias else None, device=dev)
         Fv = lambda k: sd[k].to(device=dev, dtype=f32).contiguous()
         self.nw, self.nb = Fv(p + "norm.weight"), Fv(p + "norm.bias")
         self.proj = [cw(f"projects.{i}") for i in range(4)]
@@ -127,7 +134,7 @@ class _DPT:
             w = sd[p + f"resize_layers.{i}.weight"]  # [ci, co, k, k]
             b = sd[p + f"resize_layers.{i}.bias"]
             wk = w.permute(2, 3, 1, 0)               # [dy, dx, co, ci]
-            per_dy = [ops.ConvWeight(wk[dy].reshape(k * w.shape[1], w.shape[0], 1, 1), b.repeat(k), device=dev) for dy in range(k)]
+            per_dy = [CW(wk[dy].reshape(k * w.shape[1], w.shape[0], 1, 1), b.repeat(k), device=dev) for dy in range(k)]
             self.up.append((per_dy, k, w.shape[1]))
         self.down = cw("resize_layers.3")
         s = "scratch."
@@ -173,8 +180,9 @@ class ReconEngine:
         ew = sd[c + "embed_pose.weight"].float()
         self.cam["embed_pose.weight"] = torch.nn.functional.pad(ew, (0, 3)).to(dev).contiguous()  # K 9 -> 12 (16-byte rows)
         self.cam["empty_pose_tokens"] = torch.nn.functional.pad(sd[c + "empty_pose_tokens"].float().reshape(1, 9), (0, 3)).to(dev)
-        self.depth_head = _DPT(sd, "encoder.depth_head.", dev, False)
-        self.gs_head = _DPT(sd, "encoder.gaussian_param_head.", dev, True)
+        split = cfg.dpt_precision == "f32"
+        self.depth_head = _DPT(sd, "encoder.depth_head.", dev, False, split)
+        self.gs_head = _DPT(sd, "encoder.gaussian_param_head.", dev, True, split)
         dsh = (cfg.sh_degree + 1) ** 2
         m = torch.ones(dsh)
         for d in range(1, cfg.sh_degree + 1):
@@ -328,13 +336,73 @@ class ReconEngine:
             o = rcu2_out(f, s, size)
         return ops.conv(o, hd.oc1, pad=(0, 1, 1))
 
+    # ------------------------------------------------------------------ DPT trunk, fp32-equivalent (pairs of bf16 planes)
+    def _dpt_trunk_f32(self, g, hd: _DPT, S, H, W):
+        """The same launches as _dpt_trunk on (hi, lo) pairs: ops.conv_split / layernorm_pair / bilinear_cl_pair keep every value in fp32
+        between the MFMA accumulators and the next layer's operands (dpt_head.py:185-309 under autocast off)."""
+        cfg, dev = self.cfg, self.dev
+        hp, wp, hw, Pp, nsp = g["hp"], g["wp"], g["hw"], g["Pp"], g["nsp"]
+        C2 = 2 * cfg.C
+        lv = []
+        for i, tap in enumerate(g["taps"]):
+            n = ops.layernorm_pair(tap, weight=hd.nw, bias=hd.nb, eps=1e-5, M=S * hw, in_rows=(hw, Pp - hw, nsp)).view(2, S, hp, wp, C2)
+            x = ops.conv_split(n, hd.proj[i], residual=hd.pos(hd.proj[i].CoutP, hp, wp, W, H, dev), res_row_mod=hw)
+            if i < 2:
+                per_dy, k, co = hd.up[i]
+                up = torch.empty(2, S, hp * k, wp, k * co, device=dev, dtype=bf16)
+                for dy, cwt in enumerate(per_dy):
+                    ops.conv_split(x, cwt, out=up, out_rows=(wp, (k - 1) * wp, dy * wp))
+                x = up.view(2, S, hp * k, wp * k, co)
+            elif i == 3:
+                x = ops.conv_split(x, hd.down, stride=(1, 2, 2), pad=(0, 1, 1))
+            lv.append(ops.conv_split(x, hd.rn[i], pad=(0, 1, 1), relu_out=True))
+        R = L.ACT_RELU
+
+        def rcu2_out(f, s, size):
+            c1 = ops.conv_split(s, f["c21"], pad=(0, 1, 1), act=R)
+            o = ops.conv_split(c1, f["c22"], pad=(0, 1, 1), residual=s)
+            o = ops.conv_split(o, f["out"])
+            return ops.bilinear_cl_pair(o, size, align_corners=True)
+
+        o = rcu2_out(hd.fus[4], lv[3], lv[2].shape[2:4])
+        for r, l in ((3, lv[2]), (2, lv[1]), (1, lv[0])):
+            f = hd.fus[r]
+            c1 = ops.conv_split(l, f["c11"], pad=(0, 1, 1), act=R)
+            s = ops.conv_split(c1, f["c12"], pad=(0, 1, 1), residual=l, residual2=o, relu_out=True)
+            size = lv[r - 2].shape[2:4] if r > 1 else (l.shape[2] * 2, l.shape[3] * 2)
+            o = rcu2_out(f, s, size)
+        return ops.conv_split(o, hd.oc1, pad=(0, 1, 1))
+
+    def _heads_f32(self, g, S, H, W, img: torch.Tensor, cam: torch.Tensor):
+        """img: [S,H,W,8] f32 (3 real channels, in [0,1])."""
+        dev = self.dev
+        R = L.ACT_RELU
+        d = self.depth_head
+        o = self._dpt_trunk_f32(g, d, S, H, W)
+        up = ops.bilinear_cl_pair(o, (H, W), align_corners=True, table=d.pos(o.shape[-1], H, W, W, H, dev))
+        c = ops.conv_split(up, d.oc20, pad=(0, 1, 1), act=R)
+        raw = ops.conv_split(c, d.oc22, out_f32=True).view(S * H * W, -1)
+        depth, dconf, pts = ops.depth_unproject(raw, cam, S, H, W)
+        q = self.gs_head
+        o = self._dpt_trunk_f32(g, q, S, H, W)
+        di = ops.conv_split(ops.split_f32(img), q.merger, pad=(0, 3, 3), act=R)
+        up = ops.bilinear_cl_pair(o, (H, W), align_corners=True, add=di, table=q.pos(o.shape[-1], H, W, W, H, dev))
+        c = ops.conv_split(up, q.oc20, pad=(0, 1, 1), act=R)
+        raw_gs = ops.conv_split(c, q.oc22, out_f32=True).view(S * H * W, -1)
+        return depth, dconf, pts, raw_gs
+
     def heads(self, g, S, H, W, img_cl: torch.Tensor, pose: torch.Tensor):
-        """-> depth [S,H,W], depth_conf [S,H,W], pts [S,H,W,3], raw_gs [S*H*W, 88] f32, ext [S,3,4], K [S,3,3]."""
+        """img_cl: the context image in [0,1], channels-last [S,H,W,8] (3 real channels, the rest zero), f32 or bf16 (converted to what
+        cfg.dpt_precision computes in).
+        -> depth [S,H,W], depth_conf [S,H,W], pts [S,H,W,3], raw_gs [S*H*W, 88] f32, ext [S,3,4], K [S,3,3]."""
         dev = self.dev
         ext, K = pose_encoding_to_extri_intri(pose, (H, W))
         Rt = ext[:, :, :3].transpose(1, 2)
         tinv = -(Rt * ext[:, None, :, 3]).sum(-1)   # -R^T t, elementwise (a [S,3,3] @ [S,3,1] matmul would dispatch a BLAS kernel for 9 FMAs)
         cam = torch.cat([K[:, 0, 0:1], K[:, 1, 1:2], K[:, 0, 2:3], K[:, 1, 2:3], Rt.reshape(S, 9), tinv], 1).contiguous()
+        if self.depth_head.split:
+            return (*self._heads_f32(g, S, H, W, img_cl.float().contiguous(), cam), ext, K)
+        img_cl = img_cl.to(bf16)
         R = L.ACT_RELU
         # depth head
         d = self.depth_head
@@ -398,7 +466,7 @@ class ReconEngine:
         tok = context_latent[0].permute(1, 2, 3, 0).reshape(S, hp * wp, C).to(device=self.dev, dtype=bf16)
         x.view(S, g["Pp"], C)[:, g["nsp"]:g["nsp"] + hp * wp] = (tok.float() + g["pos_patch"].float()[None]).to(bf16)
         img = (context_image[0].to(self.dev).float().permute(1, 2, 3, 0) + 1) / 2  # [S,H,W,3] in [0,1]
-        img_cl = torch.zeros(S, H, W, 8, device=self.dev, dtype=bf16)
+        img_cl = torch.zeros(S, H, W, 8, device=self.dev, dtype=f32)
         img_cl[..., :3] = img
         return self.forward_tokens_filled(S, H, W, img_cl)
 
