@@ -163,15 +163,23 @@ long v3a_conv_halo_tiles(const v3a_conv_args* args);   /* workgroups the halo ke
  *   ktab: the chunk table of the three ranges, bit 28 set where the chunk reads the LO plane of x (first range), clear for the hi plane.
  * Everything that follows the accumulation stays in fp32: v = act(acc + bias) (act NONE or RELU) + residual + residual2 ; [RELU_OUT] ;
  * stored as f32 (V3A_GEMM_OUT_F32) or split into the (y, y_lo) planes.  residual: f32 [.., ldr] with V3A_GEMM_RES_F32 (a table, see
- * res_row_mod) else a pair (c.residual, residual_lo); residual2: a pair.  c.scale, c.w_halo must be NULL; tile as in v3a_conv_bf16
- * (the halo kernel has no split form).  Geometry fields (T..pW, ups2, replicate, ldy, out_row_*) as in v3a_conv_args; both planes of a pair
- * share strides.
+ * res_row_mod) else a pair (c.residual, residual_lo); residual2: a pair.  c.scale must be NULL.  Geometry fields (T..pW, ups2, replicate,
+ * ldy, out_row_*) as in v3a_conv_args; both planes of a pair share strides.
+ * HALO-TILE form (csrc/conv_halo_split.hip) for 3x3 layers with stride 1, zero padding 1, kT = 1, Cin % 16 == 0, Cout % 32 == 0,
+ * oH % 16 == 0, oW % 32 == 0: the (hi, lo) input patch of a 16 x 32-pixel output tile is staged once in LDS, the nine taps are shifted
+ * views of it and every fragment feeds all three products.  c.w_halo = the second packing
+ *   [Cout/BN][Cin/16][9 = dh*3+dw][2 = hi, lo][BN rows n][16 k] bf16,  BN = v3a_conv_split_halo_bn(Cout)  (128, 64 or 32),
+ * where the two 16-byte chunks of a row are swapped when (n >> 3) & 1 (the kernel's LDS bank layout; slabs are copied verbatim), and
+ * c.halo_kT = 1.  Taken when w_halo is set, the layer has this form, tile < 0 and v3a_conv_split_halo_tiles(args) >= 128; tile == -2
+ * forces it, tile == -3 forbids it, tile >= 0 selects that implicit-GEMM tile.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   v3a_conv_args c;            /* x, y, residual, residual2 = the HI planes */
   const void* x_lo; void* y_lo; const void* residual_lo; const void* residual2_lo;
 } v3a_conv_split_args;
 int v3a_conv_split(const v3a_conv_split_args* args, void* stream);
+int v3a_conv_split_halo_bn(int Cout);                               /* output channels per workgroup of the halo packing; 0 = none */
+long v3a_conv_split_halo_tiles(const v3a_conv_split_args* args);    /* workgroups the halo form would launch; 0 = layer not of its form */
 /* Row / pixel passes between the split convolutions (csrc/pair.hip), fp32 arithmetic, pair in / pair out:
  *   v3a_split_f32        x f32 [n] (n % 8 == 0) -> (hi, lo)
  *   v3a_layernorm_pair   F.layer_norm of f32 rows x[row(m)][0..d) (row(m) = m + (m / in_row_group) * in_row_skip + in_row_off when

@@ -175,3 +175,43 @@ def test_bilinear_cl_pair_vs_float64(hip_lib, parity):
         e = _rel(y, ref)
         parity("bilinear_cl_pair", C=C, rel=e)
         assert e < 1e-5, (C, e)
+
+
+@pytest.mark.parametrize("cout,cin,H,W", [(256, 256, 32, 64), (128, 64, 16, 32), (64, 48, 48, 32), (32, 128, 32, 96), (96, 16, 16, 64)])
+def test_conv_split_halo_form_vs_float64(hip_lib, parity, cout, cin, H, W):
+    """the halo-tile form (csrc/conv_halo_split.hip), forced with tile=-2: every workgroup width (NJ = 4 / 2 / 1), image borders, several
+    tiles per frame, all epilogue operands; against float64 and against the implicit-GEMM form of the same layer"""
+    from vist3a_amd import lib as L
+    from vist3a_amd import ops
+    g = torch.Generator().manual_seed(cout + cin)
+    T = 2
+    x = torch.randn(T, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (cin * 9) ** -0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    r1, r2 = _pair(_cl(torch.randn(T, cout, H, W, generator=g), cout)), _pair(_cl(torch.randn(T, cout, H, W, generator=g), cout))
+    cw = ops.ConvWeightSplit(w, b)
+    assert cw.w_halo is not None
+    xp = _pair(_cl(x, cin))
+    ref = F.conv2d(ops.pair_value(xp).permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1)
+    ref = F.relu(F.relu(ref) + ops.pair_value(r1).permute(0, 3, 1, 2).double() + ops.pair_value(r2).permute(0, 3, 1, 2).double())
+    kw = dict(pad=(0, 1, 1), act=L.ACT_RELU, residual=r1.cuda(), residual2=r2.cuda(), relu_out=True)
+    yh = ops.pair_value(ops.conv_split(xp.cuda(), cw, tile=-2, **kw)).cpu().permute(0, 3, 1, 2)
+    yi = ops.pair_value(ops.conv_split(xp.cuda(), cw, tile=-3, **kw)).cpu().permute(0, 3, 1, 2)
+    e, ei, d = _rel(yh, ref), _rel(yi, ref), _rel(yh, yi)
+    parity("conv_split_halo", cout=cout, cin=cin, rel=e, implicit_rel=ei, halo_vs_implicit=d)
+    print(f"halo split {cin}->{cout} {H}x{W}: {e:.2e} vs float64 (implicit form {ei:.2e}, between them {d:.2e})")
+    assert e < 2e-5 and d < 2e-5
+    # f32 output + f32 table residual through the same kernel
+    tab = torch.randn(H * W, cout, generator=g)
+    y32 = ops.conv_split(xp.cuda(), cw, tile=-2, pad=(0, 1, 1), residual=tab.cuda(), res_row_mod=H * W, out_f32=True).cpu().permute(0, 3, 1, 2)
+    ref2 = F.conv2d(ops.pair_value(xp).permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1) + tab.double().view(1, H, W, cout).permute(0, 3, 1, 2)
+    assert _rel(y32, ref2) < 2e-5
+
+
+def test_conv_split_halo_not_eligible_is_an_error_when_forced(hip_lib):
+    from vist3a_amd import ops
+    cw = ops.ConvWeightSplit(torch.randn(32, 16, 3, 3), None)
+    xp = torch.zeros(2, 1, 8, 8, 16, dtype=bf16, device="cuda")     # 8 x 8 image: no 16 x 32 tile
+    with pytest.raises(RuntimeError):
+        ops.conv_split(xp, cw, pad=(0, 1, 1), tile=-2)
+    ops.conv_split(xp, cw, pad=(0, 1, 1))                            # automatic: implicit GEMM

@@ -954,6 +954,8 @@ extern "C" int v3a_conv_bf16(const v3a_conv_args* a, void* stream) {
 
 // fp32-equivalent convolution on the bf16 matrix pipe (include/vist3a_hip.h: v3a_conv_split): the implicit-GEMM main loop over the
 // K-concatenated partial products, fp32 epilogue.
+int v3a_conv_split_halo_launch(const v3a_conv_split_args* s, void* stream);   // conv_halo_split.hip
+
 extern "C" int v3a_conv_split(const v3a_conv_split_args* s, void* stream) {
   if (!s) return V3A_ERR_ARG;
   const v3a_conv_args* a = &s->c;
@@ -963,11 +965,16 @@ extern "C" int v3a_conv_split(const v3a_conv_split_args* s, void* stream) {
   if ((long)a->oT * a->oH * a->oW > 0x7fffffffL) return V3A_ERR_SHAPE;
   if (a->flags & ~(V3A_GEMM_RES_F32 | V3A_GEMM_OUT_F32 | V3A_GEMM_RELU_OUT)) return V3A_ERR_ARG;
   if (a->act != V3A_ACT_NONE && a->act != V3A_ACT_RELU) return V3A_ERR_ARG;
-  if (a->scale || a->w_halo) return V3A_ERR_ARG;
+  if (a->scale) return V3A_ERR_ARG;
   if (!(a->flags & V3A_GEMM_OUT_F32) && !s->y_lo) return V3A_ERR_ARG;
   if (a->residual && ((a->ldr % 8) || (!(a->flags & V3A_GEMM_RES_F32) && !s->residual_lo))) return V3A_ERR_ARG;
   if (a->residual2 && ((a->ldr2 % 8) || !s->residual2_lo)) return V3A_ERR_ARG;
   GemmP p = conv_gemm_params(a);
   p.A_lo = (const char*)s->x_lo; p.C_lo = (char*)s->y_lo; p.res_lo = (const char*)s->residual_lo; p.res2_lo = (const char*)s->residual2_lo;
+  // halo-tile form (conv_halo_split.hip) for the wide-image 3x3 layers: chosen when the layer fills at least half the chip
+  if (a->w_halo && a->tile != -3 && (a->tile == -2 || (a->tile < 0 && v3a_conv_split_halo_tiles(s) >= 128))) {
+    const int rc = v3a_conv_split_halo_launch(s, stream);
+    if (rc != V3A_ERR_SHAPE || a->tile == -2) return rc;
+  }
   return launch(p, a->tile < 0 ? -1 : a->tile, 2, stream);
 }

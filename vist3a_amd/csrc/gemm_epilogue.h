@@ -353,7 +353,8 @@ __device__ __forceinline__ void add_pair8(const u32x4 hi, const u32x4 lo, float*
 // fp32 accumulators (bias added, ReLU applied) in its private LDS region, re-reads whole rows and finishes 8 columns per lane:
 //   v = act(acc + bias) + residual (f32 table, or a (hi, lo) pair) + residual2 (pair) ; [ReLU] ; store f32, or split into the (hi, lo) planes.
 template <int MT, int NTL>
-__device__ __forceinline__ void gemm_epilogue_f32(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane, int mw0, int nw) {
+__device__ __forceinline__ void gemm_epilogue_f32(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane, int mw0, int nw,
+                                                  int gstride = 32) {   // gstride: output rows between the wave's 32-row groups (halo tiles: W)
   constexpr int WTN = NTL * 32, PITCH = WTN * 4 + 16;
   constexpr int CH = WTN / 8, ITERS = 32 * CH / 64;
   static_assert((32 * CH) % 64 == 0, "epilogue chunking");
@@ -363,7 +364,7 @@ __device__ __forceinline__ void gemm_epilogue_f32(const GemmP& p, f32x16 (&acc)[
   const bool relu_in = p.act == V3A_ACT_RELU, res_f32 = (flags & V3A_GEMM_RES_F32) != 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int mw = mw0 + i * 32;
+    const int mw = mw0 + i * gstride;
 #pragma unroll
     for (int j = 0; j < NTL; ++j)
 #pragma unroll

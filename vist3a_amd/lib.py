@@ -194,6 +194,8 @@ SYMBOLS = {
     "v3a_conv_bf16": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "v3a_conv_halo_tiles": (C.c_long, [C.POINTER(ConvArgs)]),
     "v3a_conv_split": (C.c_int, [C.POINTER(ConvSplitArgs), C.c_void_p]),
+    "v3a_conv_split_halo_bn": (C.c_int, [C.c_int]),
+    "v3a_conv_split_halo_tiles": (C.c_long, [C.POINTER(ConvSplitArgs)]),
     "v3a_split_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
     "v3a_layernorm_pair": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float] + [C.c_int] * 3 + [C.c_void_p]),
     "v3a_bilinear_cl_pair": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p]),

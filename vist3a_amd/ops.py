@@ -425,6 +425,18 @@ class ConvWeightSplit:
             b[:Cout] = bias.detach().float().cpu()
         self.bias = b.to(device)
         self.has_bias = bias is not None
+        # second packing for the halo-tile form (csrc/conv_halo_split.hip; layout at v3a_conv_split_args in the header):
+        # [Cout/BN][Cin/16][9][2 planes][BN][2 chunk positions][8], position s of row n holds chunk s ^ ((n >> 3) & 1)
+        self.w_halo = None
+        BN = 128 if self.CoutP % 128 == 0 else (64 if self.CoutP % 64 == 0 else (32 if self.CoutP % 32 == 0 else 0))
+        if kT == 1 and kH == 3 and kW == 3 and self.CinP % 16 == 0 and BN:
+            nN, nS = self.CoutP // BN, self.CinP // 16
+            planes = torch.stack([wh.float(), wl.float()])                      # [2, CoutP, 9 * CinP] (tap-major, channel-minor)
+            h = planes.reshape(2, nN, BN, 9, nS, 2, 8).permute(1, 4, 3, 0, 2, 5, 6).contiguous()   # [nN, nS, 9, 2, BN, 2 chunks, 8]
+            rot = (torch.arange(BN) >> 3) & 1
+            src = torch.arange(2)[None, :] ^ rot[:, None]                       # position s of row n <- chunk s ^ rot(n)
+            h = torch.gather(h, 5, src.view(1, 1, 1, 1, BN, 2, 1).expand(nN, nS, 9, 2, BN, 2, 8))
+            self.w_halo = h.to(device=device, dtype=bf16).contiguous()
 
 
 def conv_split(
@@ -434,7 +446,9 @@ def conv_split(
 ) -> torch.Tensor:
     """fp32-equivalent convolution (v3a_conv_split).  x: pair [2,T,H,W,CinP] -> pair [2,oT,oH,oW,CoutP] (or f32 [oT,oH,oW,CoutP] with
     out_f32).  residual: an f32 tensor (table; res_row_mod as in `conv`) or a pair; residual2: a pair.  No bf16 rounding anywhere between
-    the accumulator and the store; geometry arguments as in `conv`."""
+    the accumulator and the store; geometry arguments as in `conv`.
+    tile: -1 = automatic (the halo-tile form for wide 3x3 layers, else the implicit GEMM with a heuristic tile), >= 0 = that implicit-GEMM
+    tile, -2 = force the halo-tile form, -3 = never the halo-tile form."""
     if x.dim() != 5 or x.shape[0] != 2 or not x.is_contiguous() or x.dtype != bf16 or not x.is_cuda:
         raise ValueError("x must be a contiguous device bf16 pair [2,T,H,W,C]")
     _, T, H, W, Cin = x.shape
@@ -486,7 +500,7 @@ def conv_split(
         0, 0, o_hi.stride(0), ldr, act, flags, tile,
         _ptr(q_hi), q_hi.stride(0) if q_hi is not None else 0, res_row_mod,
         *(out_rows if out_rows is not None else (0, 0, 0)),
-        None, 0,
+        _ptr(cw.w_halo), 1 if cw.w_halo is not None else 0,
     )
     args = L.ConvSplitArgs(cargs, _ptr(x[1]), _ptr(o_lo), _ptr(r_lo), _ptr(q_lo))
     L.check(L.load().v3a_conv_split(C.byref(args), _stream()), "v3a_conv_split")
