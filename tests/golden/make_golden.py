@@ -305,7 +305,60 @@ def recon_tiny_conf():
                               "means": gs.means, "opacities": gs.opacities, "scales": gs.scales})
 
 
-GENERATORS = {f.__name__: f for f in [vae_decode_tiny, vae_encode_tiny, stitch_tiny, recon_tiny, recon_mh, recon_tiny_conf, voxel_collide]}
+def denoise_loop_ref():
+    """SURVEY row A0.  The pipeline class the reference calls (diffusers WanPipeline) is not in the image, but the reference holds ONE in-tree
+    spelling of the same CFG denoise loop: /root/reference/train_vdm.py:586-624 (B = 2 batching [cond | uncond], `pred.chunk(2)` order,
+    `noise_uncond + g (noise_pred - noise_uncond)`, `scheduler.step(noise.float(), t, latents.float())`, `latents / latents_std +
+    latents_mean`).  Its source lines are read from the reference file HERE, dedented and executed around a stub transformer
+    (tests/stub_transformer.py) and the oracle's UniPC scheduler; inputs and outputs become the fixture.  What this pins is the loop;
+    the scheduler arithmetic inside `step` stays "unpinned" (oracle/unipc.py header)."""
+    import contextlib
+    import inspect
+    import textwrap
+    from types import SimpleNamespace
+    sys.path.insert(0, str(ROOT / "tests"))
+    from stub_transformer import StubTransformer
+    import utils.wan_utils as W
+    from oracle.unipc import OracleUniPC
+    lines = (Path(_ref_import.REF) / "train_vdm.py").read_text().splitlines()
+    start = next(i for i, l in enumerate(lines) if "for i, t in tqdm(enumerate(timesteps)):" in l)
+    end = next(i for i, l in enumerate(lines) if "latents = latents / latents_std + latents_mean" in l)
+    assert 580 < start < end < 640, (start, end)        # train_vdm.py:586-624
+    block = textwrap.dedent("\n".join(lines[start:end + 1]))
+    sig = inspect.signature(W.AutoencoderKLWan.__init__).parameters
+    mean, std = sig["latents_mean"].default, sig["latents_std"].default
+    steps, shift, guidance, text_dim = 10, 5.0, 5.25, 32
+    g = torch.Generator().manual_seed(77)
+    lat0 = torch.randn(1, 16, 3, 8, 8, generator=g)
+    pe, ne = torch.randn(1, 12, text_dim, generator=g), torch.randn(1, 12, text_dim, generator=g)
+    stub = StubTransformer(text_dim)
+    osch = OracleUniPC(flow_shift=shift)
+    osch.set_timesteps(steps)
+
+    class Sched:   # diffusers' call surface over the oracle scheduler
+        timesteps = osch.timesteps
+
+        @staticmethod
+        def step(model_output, t, sample, return_dict=False):
+            assert model_output.dtype == torch.float32 and sample.dtype == torch.float32
+            return (osch.step(model_output, sample),)
+
+    ns = dict(torch=torch, tqdm=lambda it: it, accelerator=SimpleNamespace(autocast=contextlib.nullcontext),
+              pipeline=SimpleNamespace(transformer=stub, scheduler=Sched), timesteps=osch.timesteps, t_train=torch.tensor([]),
+              latents=lat0.clone(), prompt_embeds=pe, neg_prompt_embed=ne, guidance_scale=guidance,
+              latents_mean=torch.tensor(mean).view(1, 16, 1, 1, 1).float(), latents_std=1.0 / torch.tensor(std).view(1, 16, 1, 1, 1).float())
+    exec(compile(block, "train_vdm.py:586-624", "exec"), ns)
+    out = ns["latents"]
+    assert len(stub.calls) == steps and all(c == ((2, 16, 3, 8, 8), (2,), (2, 12, text_dim)) for c in stub.calls)
+    # the loop up to (not including) the de-normalisation, re-derived from the final value
+    final = (out - ns["latents_mean"]) * ns["latents_std"]
+    print(f"denoise_loop_ref: executed train_vdm.py:{start + 1}-{end + 1}; |latents| {final.abs().mean():.3f}")
+    _save("denoise_loop_ref", {"latents0": lat0, "prompt_embeds": pe, "negative_prompt_embeds": ne, "denormalised": out,
+                               "config": torch.tensor([steps, shift, guidance, text_dim], dtype=torch.float64)})
+
+
+GENERATORS = {f.__name__: f for f in [vae_decode_tiny, vae_encode_tiny, stitch_tiny, recon_tiny, recon_mh, recon_tiny_conf, voxel_collide,
+                                      denoise_loop_ref]}
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(GENERATORS)

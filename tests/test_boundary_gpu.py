@@ -57,6 +57,51 @@ def test_forward_with_latent_matches_oracle(hip_lib):
     assert out2.gaussians.means.shape[1] == S * H * H
 
 
+def test_forward_with_latent_batch_of_scenes(hip_lib):
+    """`StitchVAE3D.forward_with_latent` is batch-agnostic in the reference (stitched_model.py:165-173; the (b v) fold of
+    anysplat_stitched.py:174-202 reconstructs every scene on its own views): B = 2 equals the two B = 1 forwards scene by scene - depth,
+    poses and raw maps bit for bit, each scene's Gaussians in the leading rows of the padded batch, padding rows with opacity 0 - and
+    the feed-forward image stays fp32 through (x + 1) / 2 (:174-175): an image that is not bf16-representable gives a different
+    result from its bf16 rounding."""
+    from vist3a_amd.models.anysplat_stitched import AnySplatWeights
+    from vist3a_amd.models.stitched_model import StitchVAE3D
+    from vist3a_amd.models.stitching_layer_builder import parse_conv_spec
+    from vist3a_amd.recon.engine import ReconCfg
+    sd = R.make_recon_weights(R.ReconCfg(**RECON_TINY), seed=7)
+    model = StitchVAE3D(None, AnySplatWeights(dict(sd), ReconCfg(**RECON_TINY)), "cuda", "enc_blocks_2",
+                        parse_conv_spec("conv3d_k5x3x3_o64_s1x2x2_p2x1x1"), resolution=32)
+    g = torch.Generator().manual_seed(18)
+    model.stitching_layer.weight.data = torch.randn(64, 16, 5, 3, 3, generator=g) * 0.08
+    model.stitching_layer.bias.data = torch.randn(64, generator=g) * 0.1
+    S, H = 5, 28
+    lat = torch.randn(2, 16, 2, 4, 4, generator=g).cuda()
+    img = (torch.rand(2, 3, S, H, H, generator=g) * 2 - 1).cuda()
+    eo, anchor, conf, dconf = model.forward_with_latent(lat, img, train=True)
+    assert eo.gaussians.means.shape[0] == 2 and anchor.shape == (2, S, 83, H, H) and dconf.shape == (2, S, H, H)
+    assert eo.pred_pose_enc_list[-1].shape == (2, S, 9) and eo.depth_dict["depth"].shape == (2, S, H, H, 1)
+    U = eo.gaussians.means.shape[1]
+    counts = []
+    for b in range(2):
+        e1, a1, c1, d1 = model.forward_with_latent(lat[b:b + 1], img[b:b + 1], train=True)
+        n = e1.gaussians.means.shape[1]
+        counts.append(n)
+        assert torch.equal(eo.depth_dict["depth"][b], e1.depth_dict["depth"][0]) and torch.equal(anchor[b], a1[0]) and torch.equal(dconf[b], d1[0])
+        assert torch.equal(eo.pred_pose_enc_list[-1][b], e1.pred_pose_enc_list[-1][0])
+        assert torch.equal(eo.gaussians.means[b, :n], e1.gaussians.means[0]) and torch.equal(eo.gaussians.harmonics[b, :n], e1.gaussians.harmonics[0])
+        assert (eo.gaussians.opacities[b, n:] == 0).all()          # padded rows: density sigmoid(-1e10) = 0 (anysplat_stitched.py:440-453)
+    assert U == max(counts)
+    # fp32 image path: a perturbation below the bf16 resolution of every pixel (|x| >= 0.25: half an ulp is >= 2^-10) must still reach the
+    # Gaussian head's input_merger - it would vanish if the image were rounded to bf16 before (x + 1) / 2
+    sign = torch.where(torch.rand(1, 3, S, H, H, generator=g) < 0.5, -1.0, 1.0)
+    img1 = (sign * (0.25 + 0.75 * torch.rand(1, 3, S, H, H, generator=g))).to(torch.bfloat16).float().cuda()
+    img2 = img1 + 2.0 ** -12
+    assert torch.equal(img2.to(torch.bfloat16), img1.to(torch.bfloat16)) and not torch.equal(img2, img1)
+    d_a = model.forward_with_latent(lat[:1], img1, train=True)[1]
+    d_b = model.forward_with_latent(lat[:1], img2, train=True)[1]
+    assert not torch.equal(d_a, d_b)
+    assert torch.equal(d_a, model.forward_with_latent(lat[:1], img1, train=True)[1])    # (and the forward itself is deterministic)
+
+
 def test_image_conditioned_forward_equals_encode_then_forward_with_latent(hip_lib):
     """StitchVAE3D.forward (stitched_model.py:139-163): VAE-encode the views, sample the posterior, forward_with_latent."""
     from oracle import wan_vae as OV

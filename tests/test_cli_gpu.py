@@ -181,6 +181,12 @@ def test_loaders_apply_every_checkpoint_piece(hip_lib, tmp_path):
     sd = model.stitched_3d_model._sd
     # the two leading DINO blocks were dropped and the rest re-indexed: block 0 of the engine is block 2 of the snapshot
     assert torch.equal(sd["encoder.aggregator.patch_embed.blocks.0.norm1.weight"], a.stitched_sd["encoder.aggregator.patch_embed.blocks.0.norm1.weight"])
+    # any other stitching location drops that many leading blocks of the SAME checkpoint (anysplat_stitched.py:158-165): n_dino follows
+    m3 = load_stitching_model(SimpleNamespace(**{**vars(args), "stitching_layer_location": "enc_blocks_3"}))
+    assert m3.stitched_3d_model._cfg.n_dino == model.stitched_3d_model._cfg.n_dino - 1
+    assert torch.equal(m3.stitched_3d_model._sd["encoder.aggregator.patch_embed.blocks.0.norm1.weight"],
+                       a.stitched_sd["encoder.aggregator.patch_embed.blocks.1.norm1.weight"])
+    del m3
     # LoRA: W + (alpha / r) B A, trained bias replaces the base bias
     k = "encoder.aggregator.frame_blocks.0.attn.qkv"
     want = a.stitched_sd[k + ".weight"] + (a.lora_sd[k + ".lora_B"] @ a.lora_sd[k + ".lora_A"]) * (8 / 4)

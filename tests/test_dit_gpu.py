@@ -207,6 +207,33 @@ def test_graph_replay_is_bit_identical_across_steps_and_prompts(tiny):
     assert len(gm._graphs) == 2
 
 
+def test_graph_replay_follows_a_ctx_vo_mode_flip(tiny):
+    """`WanDiT.ctx_vo` changes what the persistent prompt buffers hold (norm_q weight folded into the cached keys, V.Wo^T instead of V^T):
+    a graph captured in one mode must not replay over the other mode's buffers.  The mode is part of the capture key."""
+    from vist3a_amd.wan.dit import GraphedWanDiT
+    ocfg, sd, model = tiny
+    gm = GraphedWanDiT(model)
+    g = torch.Generator().manual_seed(13)
+    text = (torch.randn(2, 64, ocfg.text_dim, generator=g) * 0.5).cuda()
+    text[:, 20:] = 0      # a merged padding key: the cached-context form is taken
+    lat = torch.randn(2, 16, 2, 16, 16, generator=g).to(torch.bfloat16).cuda()
+    tt = torch.tensor([500, 500]).cuda()
+    keep = model.ctx_vo
+    try:
+        outs = {}
+        for mode in (True, False, True, False):
+            model.ctx_vo = mode
+            want = model(lat, tt, text)[0].clone()
+            got = gm(lat, tt, text)[0].clone()
+            assert torch.equal(got, want), f"graph replay differs from eager with ctx_vo={mode}"
+            outs.setdefault(mode, want)
+            assert torch.equal(outs[mode], want)
+        assert len(gm._graphs) == 2
+        assert not torch.equal(outs[True], outs[False])     # the two orders of operations round differently: the flip is observable
+    finally:
+        model.ctx_vo = keep
+
+
 def test_wan14b_width_two_blocks_matches_oracle(hip_lib):
     """BASELINE config #4 geometry (Wan-14B: 40 heads x 128 = 5120 wide, FFN 13824) on two blocks: the GEMM tilings are ragged
     there (5120 / 192, 13824 / 192 are not integers) — same tolerances as the 1.3B-width forward."""

@@ -133,16 +133,27 @@ class AnySplatStitched(torch.nn.Module):
         -1e10 / points -1e4 (:440-453: a padded row has density sigmoid(-1e10) = 0, i.e. opacity 0), the Gaussian adapter over the padded
         rows, `scene_scale` taken over the whole batch (:411-412).  The reference takes the `render_conf` quantile over the whole batch as
         well (:381-387); that branch is not assembled here."""
-        from .. import ops
         eng = self.engine()
         if eng.cfg.render_conf:
             raise NotImplementedError("render_conf with batch > 1: the reference's confidence quantile spans the batch")
         B, _, S, H, W = context_image.shape
-        outs = []
-        for b in range(B):
-            o = eng.forward(context_latent[b:b + 1], context_image[b:b + 1])
-            keep = ("pred_pose_enc_list", "depth", "depth_conf", "pts_all", "raw_gs", "extrinsic_w2c", "intrinsic_px", "neural_pts", "neural_feats")
-            outs.append({k: ([t.clone() for t in o[k]] if isinstance(o[k], list) else o[k].clone()) for k in keep})   # the engine reuses its buffers
+        outs = [self.keep_scene(eng.forward(context_latent[b:b + 1], context_image[b:b + 1])) for b in range(B)]
+        return self.assemble_batch(outs, S, H, W, train)
+
+    _KEEP = ("pred_pose_enc_list", "depth", "depth_conf", "pts_all", "raw_gs", "extrinsic_w2c", "intrinsic_px", "neural_pts", "neural_feats")
+
+    @classmethod
+    def keep_scene(cls, o: dict) -> dict:
+        """copies of what the batch assembly needs from one engine forward (the engine reuses its buffers for the next scene)"""
+        return {k: ([t.clone() for t in o[k]] if isinstance(o[k], list) else o[k].clone()) for k in cls._KEEP}
+
+    def assemble_batch(self, outs, S: int, H: int, W: int, train: bool):
+        """per-scene engine outputs (keep_scene) -> the reference's batched EncoderOutput (anysplat_stitched.py:411-525)"""
+        from .. import ops
+        eng = self.engine()
+        if eng.cfg.render_conf:
+            raise NotImplementedError("render_conf with batch > 1: the reference's confidence quantile spans the batch")
+        B = len(outs)
         U = max(o["neural_feats"].shape[0] for o in outs)
         dev = outs[0]["neural_feats"].device
         gs = []

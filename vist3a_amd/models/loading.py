@@ -36,8 +36,15 @@ def load_feedforward_model(args, device) -> AnySplatWeights:
                 cfg = ReconCfg(**json.load(open(cj)).get("recon_cfg", {}))
             path = os.path.join(path, "model.safetensors")
         sd = load_file(path)
+        # the reference deletes the first k of however many DINO blocks the checkpoint holds (anysplat_stitched.py:158-165), for any k:
+        # the block count the engine runs follows from the checkpoint and the stitching location, not from a default
         k = int(args.stitching_layer_location.split("_")[-1])
-        return AnySplatWeights(sd, cfg, n_total_dino_blocks=cfg.n_dino + k)
+        pe = "encoder.aggregator.patch_embed.blocks."
+        total = len({int(q[len(pe):].split(".")[0]) for q in sd if q.startswith(pe)})
+        if total <= k:
+            raise ValueError(f"--stitching_layer_location {args.stitching_layer_location} drops {k} DINO blocks, the checkpoint holds {total}")
+        cfg.n_dino = total - k
+        return AnySplatWeights(sd, cfg, n_total_dino_blocks=total)
     if getattr(args, "checkpoint_path", None) == "synthetic":
         return AnySplatWeights(round_aggregator_to_bf16(random_recon_state_dict(cfg, seed=2, device=str(device))), cfg)
     raise FileNotFoundError("AnySplat weights: pass --anysplat_weights <local .safetensors> (the HF hub id 'lhjiang/anysplat' the "

@@ -70,13 +70,30 @@ class StitchVAE3D(torch.nn.Module):
 
     @torch.no_grad()
     def forward_with_latent(self, latent: torch.Tensor, feedforward_image: torch.Tensor, train: bool = False, image_cl: Optional[torch.Tensor] = None):
-        """latent: de-normalised VAE latent [1,16,Tl,64,64]; feedforward_image [1,3,T,448,448] in [-1,1]
-        (or, MI355X fast path, image_cl [T,448,448,8] bf16 in [-1,1] as produced by WanVAEDecoder.decode_cl + resize)."""
+        """latent: de-normalised VAE latent [B,16,Tl,64,64]; feedforward_image [B,3,T,448,448] in [-1,1]
+        (or, MI355X fast path, image_cl [T,448,448,8] in [-1,1] as produced by WanVAEDecoder.decode_cl + resize; [B,T,448,448,8] for B > 1)."""
         if latent.shape[0] != 1:
-            raise NotImplementedError("batch size 1")
+            # b > 1 (stitched_model.py:165-173 is batch-agnostic): every scene goes through exactly the b = 1 path below - stitching conv
+            # writing tokens in place, one engine forward - and the reference's batch assembly follows (AnySplatStitched.assemble_batch)
+            B = latent.shape[0]
+            if image_cl is not None and (image_cl.dim() != 5 or image_cl.shape[0] != B):
+                raise ValueError("image_cl must be [B,T,H,W,8] for a batched latent")
+            if image_cl is None and feedforward_image.shape[0] != B:
+                raise ValueError("latent and feedforward_image disagree on the batch size")
+            model = self.stitched_3d_model
+            outs, shp = [], None
+            for b in range(B):
+                o, shp = self._scene(latent[b:b + 1], None if feedforward_image is None else feedforward_image[b:b + 1],
+                                     None if image_cl is None else image_cl[b])
+                outs.append(model.keep_scene(o))
+            return model.assemble_batch(outs, *shp, train)
+        out, (S, H, W) = self._scene(latent, feedforward_image, image_cl)
+        return self.stitched_3d_model.package(out, S, H, W, train)
+
+    def _scene(self, latent: torch.Tensor, feedforward_image: Optional[torch.Tensor], image_cl: Optional[torch.Tensor]):
+        """one scene: T-upsample -> stitching conv into the token workspace -> reconstruction engine; -> (raw engine outputs, (S, H, W))"""
         st = self.stitching_layer
-        model = self.stitched_3d_model
-        eng = model.engine()
+        eng = self.stitched_3d_model.engine()
         lat_cl = ops.latent_upsample_t_cl(latent[0].to(device=self.device, dtype=torch.float32).contiguous())
         S = lat_cl.shape[0]
         if image_cl is None:
@@ -96,5 +113,4 @@ class StitchVAE3D(torch.nn.Module):
             raise ValueError(f"stitching layer output {oshape}x{cw.Cout} does not match the {S}x{g['hp']}x{g['wp']}x{eng.cfg.C} token grid")
         ops.conv(lat_cl, cw, out=x, stride=st.stride3, pad=st.padding3, out_size=tuple(oshape), replicate=True,
                  residual=g["pos_patch"], res_row_mod=hw, out_rows=(hw, Pp - hw, nsp))
-        out = eng.forward_tokens_filled(S, H, W, img01.contiguous())
-        return model.package(out, S, H, W, train)
+        return eng.forward_tokens_filled(S, H, W, img01.contiguous()), (S, H, W)

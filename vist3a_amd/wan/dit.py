@@ -598,7 +598,7 @@ class GraphedWanDiT:
         lk = self.dit._context(text)[5]  # eager: refreshes the persistent K / V^T buffers when the prompt changed
         d = self.dit   # the precision modes are baked into a capture: a flipped mode must not replay the old-precision graph
         key = (tuple(hidden_states.shape), tuple(text.shape), lk, threading.get_ident(), d.attn_dtype, d.gemm_dtype, tuple(d.fp8_scales),
-               d.merge_padding_keys, None if sp is None else (id(sp), sp.world, sp.rank, d.sp_kv_split))
+               d.merge_padding_keys, d.ctx_vo, None if sp is None else (id(sp), sp.world, sp.rank, d.sp_kv_split))
         ent = self._graphs.get(key)
         if ent is None:
             sx = torch.empty(hidden_states.shape, device=self.device, dtype=bf16)

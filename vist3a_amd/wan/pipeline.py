@@ -45,10 +45,15 @@ class WanT2VPipeline:
     # loop.  The fused loop drives the scheduler through plan_step() only: scheduler.step() is never called, so
     # `scheduler.model_outputs` / `.last_sample` are NOT updated by it (step_index / lower_order_nums are).
     fused = True
+    # How the guided prediction enters `scheduler.step`.  False (default) = diffusers' WanPipeline, the call the inference path makes
+    # (/root/reference/inference_t23d.py:94-103): the prediction stays in the transformer's dtype, so the scheduler's `sigma * v` is rounded to
+    # bf16.  True = the reference's in-tree training roll-out, `scheduler.step(noise_pred.float(), t, latents.float())`
+    # (/root/reference/train_vdm.py:620-622): fp32 product.  The two reference loops differ in exactly this cast (tensor-op loop only).
+    scheduler_inputs_fp32 = False
 
     def _can_fuse(self, callback) -> bool:
         sch, tr = self.scheduler, self.transformer
-        return (self.fused and self.plan is None and callback is None and hasattr(tr, "token_buffers")
+        return (self.fused and not self.scheduler_inputs_fp32 and self.plan is None and callback is None and hasattr(tr, "token_buffers")
                 and tuple(getattr(tr.cfg, "patch_size", ())) == (1, 2, 2) and hasattr(sch, "plan_step")
                 and getattr(sch, "solver_order", 3) <= 2)
 
@@ -138,6 +143,8 @@ class WanT2VPipeline:
             elif do_cfg:
                 n_c, n_u = noise[0:1], noise[1:2]
                 noise = n_u + guidance_scale * (n_c - n_u)  # bf16 arithmetic, as the reference pipeline
+            if self.scheduler_inputs_fp32:
+                noise = noise.float()
             latents = self.scheduler.step(noise, t, latents, return_dict=False)[0]
             if callback is not None:
                 callback(i, t, latents)
