@@ -326,12 +326,14 @@ def merged_padding_keys(text: torch.Tensor):
 def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.Tensor, timestep: torch.Tensor,
                 text: torch.Tensor, emulate_bf16: bool = False, num_layers: int | None = None, fp8_attn: bool = False,
                 fp8_gemm: bool = False, flash: bool = False, merge_padding: bool = False, fp16_norm: bool = False,
-                depth_outputs: dict | None = None, ctx_vo: bool = False) -> torch.Tensor:
+                depth_outputs: dict | None = None, ctx_vo: bool = False, hidden_trace: list | None = None) -> torch.Tensor:
     """transformer(hidden_states[B,16,T,H,W], timestep[B], encoder_hidden_states[B,L,4096]) -> [B,16,T,H,W].
     `flash` / `merge_padding` switch on the two places where the HIP path's CONTRACT differs from exact softmax over all 512 context
     rows (bf16 P per 64-key tile; one merged zero-padding key) so that a full-depth comparison measures the kernels, not those.
     `depth_outputs` = {L: None, ...}: filled with the model output truncated after L blocks (== num_layers=L), for error-vs-depth curves.
-    `ctx_vo`: the cross-attention in the product's cached-context form (cross_attention_ctx_vo) - its third contract difference."""
+    `ctx_vo`: the cross-attention in the product's cached-context form (cross_attention_ctx_vo) - its third contract difference.
+    `hidden_trace` (a list): receives the residual stream [B, N, d] in front of block 0 and behind every block (len = L + 1) - the inputs
+    and expected outputs of per-block teacher-forced comparisons."""
     emu = emulate_bf16
     ctx_keys = merged_padding_keys(text) if merge_padding else None
     B, C, Fr, Hh, Ww = latents.shape
@@ -348,8 +350,12 @@ def dit_forward(sd: Dict[str, torch.Tensor], cfg: WanDiTConfig, latents: torch.T
         h = _r(F.layer_norm(h.float(), (cfg.dim,), eps=cfg.eps) * (1 + scale) + shift, emu)
         return unpatchify(cfg, _lin(h, sd, "proj_out", emu), Fr, Hh, Ww)
 
+    if hidden_trace is not None:
+        hidden_trace.append(x.clone())
     for i in range(L):
         x = block_forward(sd, cfg, i, x, ctx, tproj, freqs, emu, fp8_attn, fp8_gemm, flash, ctx_keys, fp16_norm, ctx_vo)
+        if hidden_trace is not None:
+            hidden_trace.append(x.clone())
         if depth_outputs is not None and (i + 1) in depth_outputs:
             depth_outputs[i + 1] = head(x)      # what dit_forward(num_layers=i+1) returns, from the one pass
     return head(x)

@@ -128,31 +128,40 @@ def resample(sd, p, x, mode):
     return y.view(B, T, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
 
 
-def decode(sd: Dict[str, torch.Tensor], cfg: WanVAEConfig, z: torch.Tensor, emulate_bf16: bool = False) -> torch.Tensor:
+def decode(sd: Dict[str, torch.Tensor], cfg: WanVAEConfig, z: torch.Tensor, emulate_bf16: bool = False, trace: list = None) -> torch.Tensor:
     """AutoencoderKLWan._decode: z [B,16,T_lat,h,w] (de-normalised latents) -> video [B,3,1+4(T_lat-1),8h,8w] in [-1,1].
-    emulate_bf16: the CUDA-autocast rounding points (module docstring)."""
+    emulate_bf16: the CUDA-autocast rounding points (module docstring).
+    `trace` (a list): receives (name, input, output) of every residual block, the attention block and every upsampler - the inputs and
+    expected outputs of per-layer teacher-forced comparisons."""
     global _EMU
     prev, _EMU = _EMU, bool(emulate_bf16)
     try:
-        return _decode(sd, cfg, z)
+        return _decode(sd, cfg, z, trace)
     finally:
         _EMU = prev
 
 
-def _decode(sd, cfg, z):
+def _decode(sd, cfg, z, trace=None):
     sd = {k: v.float() for k, v in sd.items()}
+
+    def rec(name, fn, x, *a):
+        y = fn(sd, name, x, *a)
+        if trace is not None:
+            trace.append((name, x, y))
+        return y
+
     x = causal_conv3d(z.float(), sd["post_quant_conv.weight"], sd["post_quant_conv.bias"], (0, 0, 0))
     d = "decoder."
     x = causal_conv3d(x, sd[d + "conv_in.weight"], sd[d + "conv_in.bias"], (1, 1, 1))
-    x = res_block(sd, d + "mid_block.resnets.0.", x)
-    x = attn_block(sd, d + "mid_block.attentions.0.", x)
-    x = res_block(sd, d + "mid_block.resnets.1.", x)
+    x = rec(d + "mid_block.resnets.0.", res_block, x)
+    x = rec(d + "mid_block.attentions.0.", attn_block, x)
+    x = rec(d + "mid_block.resnets.1.", res_block, x)
     _, plan = cfg.decoder_plan()
     for i, (_, _, mode) in enumerate(plan):
         for j in range(cfg.num_res_blocks + 1):
-            x = res_block(sd, d + f"up_blocks.{i}.resnets.{j}.", x)
+            x = rec(d + f"up_blocks.{i}.resnets.{j}.", res_block, x)
         if mode is not None:
-            x = resample(sd, d + f"up_blocks.{i}.upsamplers.0.", x, mode)
+            x = rec(d + f"up_blocks.{i}.upsamplers.0.", resample, x, mode)
     x = F.silu(rms_norm(x, sd[d + "norm_out.gamma"]))
     x = causal_conv3d(x, sd[d + "conv_out.weight"], sd[d + "conv_out.bias"], (1, 1, 1))
     return torch.clamp(x, -1.0, 1.0)

@@ -1,0 +1,120 @@
+"""The three production-size oracle cases whose outputs are committed as digests (tests/oracle_cache.py): seeded inputs, weights and the
+oracle computation of each, with NO dependence on the GPU or on the HIP library - `tests/golden/make_fullsize_oracle.py` runs exactly
+these on host cores to write the digests, and the `-m gpu` tests build the same case to get the same inputs and the digest's fingerprint.
+Each case carries the oracle modules whose SOURCE is hashed into the fingerprint: editing oracle/recon.py or oracle/wan_dit.py (or this
+file) invalidates the committed digest loudly instead of leaving a stale golden that still "matches"."""
+from __future__ import annotations
+
+import time
+from types import SimpleNamespace
+
+import torch
+
+import oracle_cache as OC
+from oracle import recon as R
+from oracle import wan_dit as O
+
+RECON_MH = dict(C=128, heads=2, n_dino=22, depth=24, cam_heads=4, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+DIT_DEPTHS = (1, 2, 4, 8, 16, 30)
+
+
+def recon_full_weights():
+    """Width-1024 / 16-head reconstruction weights from the oracle's seeded generator (LayerScale 0.3 in the aggregator: every block
+    contributes, unlike the 0.01 of bench.py's reference-style initialisation), aggregator values bf16-representable like the
+    reference's bf16-stored aggregator (anysplat.py:144)."""
+    from vist3a_amd.recon.weights import round_aggregator_to_bf16
+    cfg = R.ReconCfg()
+    assert (cfg.C, cfg.heads, cfg.cam_heads) == (1024, 16, 16)
+    return cfg, round_aggregator_to_bf16(R.make_recon_weights(cfg, seed=51))
+
+
+def recon_full(weights=None) -> SimpleNamespace:
+    """13 views @448, width 1024: tests/test_fullsize_gpu.py::test_full_size_reconstruction_matches_oracle"""
+    ocfg, sd = weights if weights is not None else recon_full_weights()
+    g = torch.Generator().manual_seed(52)
+    w = (torch.randn(1024, 16, 5, 3, 3, generator=g) * 0.08).to(torch.bfloat16).float()
+    b = torch.randn(1024, generator=g) * 0.1
+    lat = torch.randn(1, 16, 4, 64, 64, generator=g)
+    img = (torch.rand(1, 3, 13, 448, 448, generator=g) * 2 - 1).to(torch.bfloat16).float()
+    S, H = 13, 448
+
+    def compute():
+        t0 = time.time()
+        feat_c = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
+        ctaps = R.backbone(sd, feat_c, 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth, emulate_bf16=True)
+        t1 = time.time()
+        ora = R.recon_forward(sd, ocfg, feat_c, img, toks=ctaps)
+        t2 = time.time()
+        # plain fp32 backbone as well (informational: how far the reference's own rounding points move the taps)
+        ftaps = R.backbone(sd, R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1)), 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth)
+        t3 = time.time()
+        d = {f"tap{i}": c[0] for i, c in enumerate(ctaps)}
+        d.update({f"tap{i}_fp32": c[0] for i, c in enumerate(ftaps)})
+        d.update(pose=ora["pred_pose_enc_list"][-1], depth=ora["depth"], depth_conf=ora["depth_conf"], raw_gs=ora["raw_gs"][:, :, :83],
+                 gs_conf=ora["raw_gs"][:, :, 83], c2w=ora["pred_context_pose"]["extrinsic"], intrinsic=ora["pred_context_pose"]["intrinsic"],
+                 voxels=ora["gaussians"]["means"].shape[1], seconds_backbone_contract=t1 - t0, seconds_heads=t2 - t1, seconds_backbone_fp32=t3 - t2)
+        return d
+
+    fp = OC.checksum(lat, img, w, b, sd["encoder.aggregator.frame_blocks.0.attn.qkv.weight"], sd["encoder.gaussian_param_head.scratch.output_conv2.2.weight"])
+    return SimpleNamespace(name="recon_full_C1024_S13", fingerprint=fp, sources=(R,), compute=compute, ocfg=ocfg, sd=sd, w=w, b=b, lat=lat, img=img, S=S, H=H)
+
+
+def recon_config3() -> SimpleNamespace:
+    """21 views @448 at width 128: tests/test_fullsize_gpu.py::test_config3_21_view_reconstruction_layout_matches_oracle"""
+    ocfg = R.ReconCfg(**RECON_MH)
+    sd = R.make_recon_weights(ocfg, seed=71)
+    g = torch.Generator().manual_seed(72)
+    w = torch.randn(128, 16, 5, 3, 3, generator=g) * 0.08
+    b = torch.randn(128, generator=g) * 0.1
+    S, H = 21, 448
+    lat = torch.randn(1, 16, 6, 64, 64, generator=g)
+    img = torch.rand(1, 3, S, H, H, generator=g) * 2 - 1
+
+    def compute():
+        feat = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
+        ora = R.recon_forward(sd, ocfg, feat, img, emulate_bf16=True)                       # the reference's GPU rounding points, fp32 heads
+        dev = R.recon_forward(sd, ocfg, feat, img, dpt_bf16=True, toks=ora["taps"])         # + bf16 DPT heads (the opt-in dpt_precision="bf16")
+        o32 = R.recon_forward(sd, ocfg, R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1)), img)   # plain fp32 (informational)
+        d = {}
+        for tag, o in (("c", ora), ("d", dev), ("f", o32)):
+            d.update({f"{tag}_pose": o["pred_pose_enc_list"][-1], f"{tag}_depth": o["depth"], f"{tag}_depth_conf": o["depth_conf"],
+                      f"{tag}_raw_gs": o["raw_gs"][:, :, :83], f"{tag}_raw_all": o["raw_gs"]})
+        d.update({f"c_tap{i}": c[0] for i, c in enumerate(ora["taps"])})
+        d.update({f"f_tap{i}": c[0] for i, c in enumerate(o32["taps"])})
+        d["voxels"] = ora["gaussians"]["means"].shape[1]
+        return d
+
+    fp = OC.checksum(lat, img, w, b, sd["encoder.aggregator.frame_blocks.0.attn.qkv.weight"])
+    return SimpleNamespace(name="recon_config3_S21_width128", fingerprint=fp, sources=(R,), compute=compute, ocfg=ocfg, sd=sd, w=w, b=b, lat=lat, img=img,
+                           S=S, H=H)
+
+
+def dit_full_depth() -> SimpleNamespace:
+    """Wan-1.3B geometry, 30 blocks, 4096 tokens: tests/test_dit_gpu.py::test_full_depth_production_size_forward_matches_oracle"""
+    ocfg = O.WanDiTConfig(num_attention_heads=12, attention_head_dim=128, ffn_dim=8960, num_layers=30, text_dim=512, freq_dim=256)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=11).items()}
+    g = torch.Generator().manual_seed(12)
+    lat = torch.randn(1, 16, 4, 64, 64, generator=g).to(torch.bfloat16)
+    text = (torch.randn(1, 512, ocfg.text_dim, generator=g) * 0.5).to(torch.bfloat16).float()
+    text[:, 77:] = 0
+    t = torch.tensor([700])
+
+    def compute():
+        ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
+        # the same forward with the CONTRACT differences of the HIP path emulated as well: bf16 P per 64-key flash tile (every flash
+        # kernel has that term, the reference's SDPA included), the merged zero-padding key of the cross-attention, and the
+        # cross-attention's cached-context order of operations (ctx_vo)
+        taps = {L: None for L in DIT_DEPTHS}
+        ref_c = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True, depth_outputs=taps)
+        d = dict(ref=ref, ref_c=ref_c, ref_rms=ref.pow(2).mean().sqrt().item())
+        d.update({f"depth{L}": taps[L] for L in DIT_DEPTHS})
+        return d
+
+    fp = OC.checksum(lat, text, sd["blocks.0.attn1.to_q.weight"], sd["blocks.29.ffn.net.2.weight"])
+    return SimpleNamespace(name="dit_full_depth_30_blocks_N4096", fingerprint=fp, sources=(O,), compute=compute, ocfg=ocfg, sd=sd, lat=lat, text=text, t=t)
+
+
+CASES = {"recon_full": recon_full, "recon_config3": recon_config3, "dit_full_depth": dit_full_depth}
+# digest name -> oracle modules whose source it depends on (what each case passes as `sources`; lets a CPU test check every committed
+# digest against the current sources without building the cases' gigabytes of weights)
+SOURCES = {"recon_full_C1024_S13": (R,), "recon_config3_S21_width128": (R,), "dit_full_depth_30_blocks_N4096": (O,)}

@@ -253,6 +253,70 @@ def test_wan14b_width_two_blocks_matches_oracle(hip_lib):
     assert torch.isfinite(out.float()).all() and r < 1.06e-2, r   # measured 5.3e-3
 
 
+def test_config4_14b_width_eight_blocks_match_oracle(hip_lib, parity):
+    """BASELINE config #4 (Wan-14B stitched, fp8 MFMA attention) on EIGHT of its 40 blocks, 1024 tokens per batch item, B = 2: the bf16
+    mode against the contract oracle and the fp8-attention mode against the oracle with the e4m3 rounding points emulated - with the
+    error-vs-depth curve of both, so a defect that only compounds shows."""
+    from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
+    kw = dict(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=8, text_dim=256, freq_dim=256)
+    ocfg = O.WanDiTConfig(**kw)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=44).items()}
+    model = WanDiT(WanDiTConfig(**kw), sd, device="cuda")
+    g = torch.Generator().manual_seed(45)
+    lat = torch.randn(2, 16, 1, 64, 64, generator=g).to(torch.bfloat16)   # 1024 tokens per item
+    text = (torch.randn(2, 96, 256, generator=g) * 0.5).to(torch.bfloat16).float()
+    text[0, 60:] = 0
+    text[1, 70:] = 0
+    t = torch.tensor([611, 611])
+    depths = (1, 2, 4, 8)
+    taps16, taps8 = {L: None for L in depths}, {L: None for L in depths}
+    with torch.no_grad():
+        O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True, depth_outputs=taps16)
+        O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, merge_padding=True, ctx_vo=True, depth_outputs=taps8)
+    c16 = {L: _rel(model(lat.cuda(), t.cuda(), text.cuda(), num_layers=L)[0], taps16[L]) for L in depths}
+    model.attn_dtype = "fp8"
+    c8 = {L: _rel(model(lat.cuda(), t.cuda(), text.cuda(), num_layers=L)[0], taps8[L]) for L in depths}
+    parity("dit_config4_14B_width_8_blocks", bf16_vs_contract_by_depth={str(k): v for k, v in c16.items()},
+           fp8_attention_vs_e4m3_oracle_by_depth={str(k): v for k, v in c8.items()})
+    print("config #4, 14B width, by depth: bf16", {k: f"{v:.2e}" for k, v in c16.items()}, "fp8 attention", {k: f"{v:.2e}" for k, v in c8.items()})
+    assert c16[1] < TOL_ONE_BLOCK and c8[1] < 2 * TOL_ONE_BLOCK, (c16, c8)
+    assert c16[8] < 1.2e-2 and c8[8] < 2.4e-2, (c16, c8)     # measured 5.6e-3 / 1.1e-2 after eight blocks
+
+
+def test_config4_full_depth_14b_forward_is_deterministic_and_finite(hip_lib, parity):
+    """The whole 40-block Wan-14B forward at config #4's geometry (13 views @512 = 4096 tokens, CFG batch 2), bf16 and fp8-attention modes:
+    finite, bounded, bit-identical run to run, and the two modes within fp8's price of each other (no oracle at this size - 28 GB of
+    weights; size-independent properties only)."""
+    from vist3a_amd.wan.dit import WAN_14B, WanDiT
+    from vist3a_amd.wan.weights import random_dit_state_dict
+    import dataclasses
+    cfg = dataclasses.replace(WAN_14B, text_dim=512)
+    model = WanDiT(cfg, random_dit_state_dict(cfg, seed=0, device="cuda"))
+    assert cfg.num_layers == 40 and cfg.num_attention_heads == 40
+    g = torch.Generator().manual_seed(46)
+    lat = torch.randn(1, 16, 4, 64, 64, generator=g).to(torch.bfloat16).cuda().expand(2, -1, -1, -1, -1).contiguous()
+    text = (torch.randn(2, 512, 512, generator=g) * 0.1).cuda()
+    text[0, 77:] = 0
+    text[1, 9:] = 0
+    t = torch.tensor([700, 700]).cuda()
+    a16 = model(lat, t, text)[0].clone()
+    b16 = model(lat, t, text)[0].clone()
+    model.attn_dtype = "fp8"
+    a8 = model(lat, t, text)[0].clone()
+    b8 = model(lat, t, text)[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a16, b16) and torch.equal(a8, b8)
+    assert torch.isfinite(a16.float()).all() and torch.isfinite(a8.float()).all()
+    assert not torch.equal(a16[0], a16[1])                         # the two prompts condition the two batch items differently
+    shift = _rel(a8, a16)
+    rms = a16.float().pow(2).mean().sqrt().item()
+    parity("dit_config4_14B_40_blocks_N4096", rms=rms, fp8_attention_vs_bf16=shift, deterministic=True, peak_GB=torch.cuda.max_memory_allocated() / 2 ** 30)
+    print(f"14B 40-block forward: rms {rms:.3f}, fp8-attention vs bf16 {shift:.2e}, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GB")
+    assert 1e-3 < rms < 1e3 and 0 < shift < 0.2
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_21_view_latent_shapes(tiny):
     """BASELINE config #3 geometry: 21 views = 6 latent frames (6144 tokens at 64x64 latents; here 6 x 16 x 16 = 384)."""
     ocfg, sd, model = tiny
@@ -368,35 +432,19 @@ def test_full_depth_production_size_forward_matches_oracle(hip_lib, parity):
     flash kernel run inside the model AND are compared with a reference.  Text context 77 tokens + padding to 512 (merged)."""
     import dataclasses
     from vist3a_amd.wan.dit import WAN_1_3B, WanDiT
+    import fullsize_cases as FC
+    import oracle_cache as OC
+    case = FC.dit_full_depth()
     cfg = dataclasses.replace(WAN_1_3B, text_dim=512)   # UMT5 width 4096 only scales the (cached) context MLP
-    ocfg = O.WanDiTConfig(num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim, ffn_dim=cfg.ffn_dim,
-                          num_layers=cfg.num_layers, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim)
-    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=11).items()}
+    ocfg, sd, lat, text, t = case.ocfg, case.sd, case.lat, case.text, case.t
+    assert (ocfg.num_attention_heads, ocfg.ffn_dim, ocfg.num_layers, ocfg.freq_dim) == (cfg.num_attention_heads, cfg.ffn_dim, cfg.num_layers, cfg.freq_dim)
     model = WanDiT(cfg, sd, device="cuda")
-    g = torch.Generator().manual_seed(12)
-    lat = torch.randn(1, 16, 4, 64, 64, generator=g).to(torch.bfloat16)
-    text = (torch.randn(1, 512, cfg.text_dim, generator=g) * 0.5).to(torch.bfloat16).float()
-    text[:, 77:] = 0
-    t = torch.tensor([700])
-    depths = (1, 2, 4, 8, 16, 30)
+    depths = FC.DIT_DEPTHS
     outs = {L: model(lat.cuda(), t.cuda(), text.cuda(), num_layers=L)[0].float().cpu() for L in depths}
     out = outs[30]
     torch.cuda.synchronize()
-    import oracle_cache as OC
-
-    def compute():
-        ref = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True)
-        # the same forward with the CONTRACT differences of the HIP path emulated as well: bf16 P per 64-key flash tile (every flash
-        # kernel has that term, the reference's SDPA included), the merged zero-padding key of the cross-attention, and the
-        # cross-attention's cached-context order of operations (ctx_vo)
-        taps = {L: None for L in depths}
-        ref_c = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True, depth_outputs=taps)
-        d = dict(ref=ref, ref_c=ref_c, ref_rms=ref.pow(2).mean().sqrt().item())
-        d.update({f"depth{L}": taps[L] for L in depths})
-        return d
-
     # (the two 30-block oracle forwards take ~2 minutes of host time: committed digest, tests/oracle_cache.py)
-    od, live = OC.oracle("dit_full_depth_30_blocks_N4096", OC.checksum(lat, text, sd["blocks.0.attn1.to_q.weight"], sd["blocks.29.ffn.net.2.weight"]), compute)
+    od, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources)
     r, rc, floor = OC.rel(out, od["ref"]), OC.rel(out, od["ref_c"]), OC.rel_dd(od["ref_c"], od["ref"])
     curve = {L: OC.rel(outs[L], od[f"depth{L}"]) for L in depths}
     mx = (OC.digest(out) - od["ref"]).abs().max().item()

@@ -16,6 +16,7 @@ import torch
 from oracle import recon as R
 from oracle import wan_dit as O
 from oracle import wan_vae as OV
+import fullsize_cases as FC
 import oracle_cache as OC
 
 pytestmark = pytest.mark.gpu
@@ -73,13 +74,8 @@ VAE_FULL_GATE = 2.9e-2    # <= 2x the measured HIP-vs-contract figure (1.48e-2 o
 
 @pytest.fixture(scope="module")
 def recon_full(hip_lib):
-    """Width-1024 / 16-head reconstruction weights from the oracle's seeded generator (LayerScale 0.3 in the aggregator: every block
-    contributes, unlike the 0.01 of bench.py's reference-style initialisation), aggregator values bf16-representable like the
-    reference's bf16-stored aggregator (anysplat.py:144)."""
-    from vist3a_amd.recon.weights import round_aggregator_to_bf16
-    cfg = R.ReconCfg()
-    assert (cfg.C, cfg.heads, cfg.cam_heads) == (1024, 16, 16)
-    return cfg, round_aggregator_to_bf16(R.make_recon_weights(cfg, seed=51))
+    """Width-1024 / 16-head reconstruction weights (tests/fullsize_cases.py::recon_full_weights)"""
+    return FC.recon_full_weights()
 
 
 def _stitched(sd, rcfg_kw, C, res=512):
@@ -97,41 +93,16 @@ def test_full_size_reconstruction_matches_oracle(recon_full, parity):
     fp32 LayerNorm, bf16 DINO stream, fp32 aggregator stream, fp32 heads - oracle/recon.py docstring).  One oracle pass (backbone in
     contract mode, fp32 heads on its taps); the figures against the plain fp32 oracle (round 3: taps 9.2e-3 .. 7.1e-3) are informational and
     taken in the 21-view layout test below, where all three oracle forms run in a minute."""
-    import time
-    ocfg, sd = recon_full
+    case = FC.recon_full(recon_full)
+    ocfg, sd, w, b, lat, img, S, H = case.ocfg, case.sd, case.w, case.b, case.lat, case.img, case.S, case.H
     model = _stitched(sd, {}, 1024)
-    g = torch.Generator().manual_seed(52)
-    w = (torch.randn(1024, 16, 5, 3, 3, generator=g) * 0.08).to(torch.bfloat16).float()
-    b = torch.randn(1024, generator=g) * 0.1
     model.stitching_layer.weight.data, model.stitching_layer.bias.data = w, b
-    lat = torch.randn(1, 16, 4, 64, 64, generator=g)
-    img = (torch.rand(1, 3, 13, 448, 448, generator=g) * 2 - 1).to(torch.bfloat16).float()
-    S, H = 13, 448
     eo, anchor, conf, dconf = model.forward_with_latent(lat.cuda(), img.cuda(), train=True)
     torch.cuda.synchronize()
     eng = model.stitched_3d_model.engine()
     _, geo = eng.token_workspace(S, H, H)
     taps = [t.view(S, geo["Pp"], -1)[:, :geo["P"]].float().cpu() for t in geo["taps"]]
-
-    def compute():
-        t0 = time.time()
-        feat_c = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
-        ctaps = R.backbone(sd, feat_c, 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth, emulate_bf16=True)
-        t1 = time.time()
-        ora = R.recon_forward(sd, ocfg, feat_c, img, toks=ctaps)
-        t2 = time.time()
-        # plain fp32 backbone as well (informational: how far the reference's own rounding points move the taps)
-        ftaps = R.backbone(sd, R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1)), 1, S, (H, H), ocfg.heads, ocfg.n_dino, ocfg.depth)
-        t3 = time.time()
-        d = {f"tap{i}": c[0] for i, c in enumerate(ctaps)}
-        d.update({f"tap{i}_fp32": c[0] for i, c in enumerate(ftaps)})
-        d.update(pose=ora["pred_pose_enc_list"][-1], depth=ora["depth"], depth_conf=ora["depth_conf"], raw_gs=ora["raw_gs"][:, :, :83],
-                 gs_conf=ora["raw_gs"][:, :, 83], c2w=ora["pred_context_pose"]["extrinsic"], intrinsic=ora["pred_context_pose"]["intrinsic"],
-                 voxels=ora["gaussians"]["means"].shape[1], seconds_backbone_contract=t1 - t0, seconds_heads=t2 - t1, seconds_backbone_fp32=t3 - t2)
-        return d
-
-    ora, live = OC.oracle("recon_full_C1024_S13", OC.checksum(lat, img, w, b, sd["encoder.aggregator.frame_blocks.0.attn.qkv.weight"],
-                                                               sd["encoder.gaussian_param_head.scratch.output_conv2.2.weight"]), compute)
+    ora, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources)
     tap_c = [OC.rel(t, ora[f"tap{i}"]) for i, t in enumerate(taps)]
     tap_32 = [OC.rel(t, ora[f"tap{i}_fp32"]) for i, t in enumerate(taps)]
     floor = [OC.rel_dd(ora[f"tap{i}"], ora[f"tap{i}_fp32"]) for i in range(len(taps))]
@@ -186,43 +157,22 @@ def test_config3_21_view_dit_forward_matches_oracle(hip_lib, parity):
     assert r < 5.2e-3, r     # measured 2.6e-3 (round 3 also ran the plain fp32 oracle: 5.0e-3, profiles/r3/parity.json)
 
 
-RECON_MH = dict(C=128, heads=2, n_dino=22, depth=24, cam_heads=4, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+RECON_MH = FC.RECON_MH
 
 
 def test_config3_21_view_reconstruction_layout_matches_oracle(hip_lib, parity):
     """The 21-view token layout at FULL resolution (21 x 1032 padded rows, 1029 valid; global attention over 21 609 keys with the
     per-view mask; 21 x 448^2 = 4.2 M points into the voxeliser) at width 128 / two heads so that the oracle finishes in a minute."""
-    ocfg = R.ReconCfg(**RECON_MH)
-    sd = R.make_recon_weights(ocfg, seed=71)
+    case = FC.recon_config3()
+    ocfg, sd, w, b, lat, img, S, H = case.ocfg, case.sd, case.w, case.b, case.lat, case.img, case.S, case.H
     model = _stitched(sd, RECON_MH, 128)
-    g = torch.Generator().manual_seed(72)
-    w = torch.randn(128, 16, 5, 3, 3, generator=g) * 0.08
-    b = torch.randn(128, generator=g) * 0.1
     model.stitching_layer.weight.data, model.stitching_layer.bias.data = w, b
-    S, H = 21, 448
-    lat = torch.randn(1, 16, 6, 64, 64, generator=g)
-    img = torch.rand(1, 3, S, H, H, generator=g) * 2 - 1
     eo, anchor, conf, dconf = model.forward_with_latent(lat.cuda(), img.cuda(), train=True)
     torch.cuda.synchronize()
     eng = model.stitched_3d_model.engine()
     _, geo = eng.token_workspace(S, H, H)
     taps = [t_.view(S, geo["Pp"], -1)[:, :geo["P"]].float().cpu() for t_ in geo["taps"]]
-
-    def compute():
-        feat = R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1), emulate_bf16=True)
-        ora = R.recon_forward(sd, ocfg, feat, img, emulate_bf16=True)                       # the reference's GPU rounding points, fp32 heads
-        dev = R.recon_forward(sd, ocfg, feat, img, dpt_bf16=True, toks=ora["taps"])         # + the HIP path's documented bf16 DPT heads
-        o32 = R.recon_forward(sd, ocfg, R.stitch_conv(R.upsample_T(lat), w, b, (1, 2, 2), (2, 1, 1)), img)   # plain fp32 (informational)
-        d = {}
-        for tag, o in (("c", ora), ("d", dev), ("f", o32)):
-            d.update({f"{tag}_pose": o["pred_pose_enc_list"][-1], f"{tag}_depth": o["depth"], f"{tag}_depth_conf": o["depth_conf"],
-                      f"{tag}_raw_gs": o["raw_gs"][:, :, :83], f"{tag}_raw_all": o["raw_gs"]})
-        d.update({f"c_tap{i}": c[0] for i, c in enumerate(ora["taps"])})
-        d.update({f"f_tap{i}": c[0] for i, c in enumerate(o32["taps"])})
-        d["voxels"] = ora["gaussians"]["means"].shape[1]
-        return d
-
-    od, live = OC.oracle("recon_config3_S21_width128", OC.checksum(lat, img, w, b, sd["encoder.aggregator.frame_blocks.0.attn.qkv.weight"]), compute)
+    od, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources)
     errs = lambda tag: dict(pose=OC.rel(eo.pred_pose_enc_list[-1], od[tag + "_pose"]), depth=OC.rel(eo.depth_dict["depth"], od[tag + "_depth"]),
                             depth_conf=OC.rel(dconf, od[tag + "_depth_conf"]), raw_gs=OC.rel(anchor, od[tag + "_raw_gs"]))
     e, ed, e32 = errs("c"), errs("d"), errs("f")

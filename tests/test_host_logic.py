@@ -393,3 +393,22 @@ def test_bench_parses_the_rocm_smi_clock_and_power_sample():
     assert bench.parse_rocm_smi('{"card0": {"sclk clock level:": "S"}}') is None
     assert bench.parse_rocm_smi("ERROR: no GPU") is None and bench.parse_rocm_smi("") is None
     assert bench.parse_rocm_smi('{"card0": {"sclk clock speed:": "(95Mhz)", "Average Graphics Package Power (W)": "N/A"}}') is None
+
+
+def test_committed_oracle_digests_match_the_current_oracle_sources():
+    """tests/oracle_cache.py: every committed full-size digest carries the sha256 of the oracle sources that computed it; an edit of
+    oracle/recon.py / oracle/wan_dit.py (or of the case definitions) without regenerating the digests fails HERE, on the CPU, not only
+    when the GPU suite next reads them."""
+    import sys
+    from pathlib import Path
+    from safetensors import safe_open
+    sys.path.insert(0, str(Path(__file__).parent))
+    import fullsize_cases as FC
+    import oracle_cache as OC
+    files = sorted(OC.GOLD.glob("oracle_*.safetensors"))
+    assert {f.stem[len("oracle_"):] for f in files} == set(FC.SOURCES)
+    for f in files:
+        meta = safe_open(str(f), "pt").metadata() or {}
+        name = f.stem[len("oracle_"):]
+        assert meta.get("oracle_sources_sha256") == OC.source_hash(FC.SOURCES[name]), f"{f.name} is stale: re-run tests/golden/make_fullsize_oracle.py"
+        assert meta.get("generated_without_gpu") == "True", f"{f.name} was not written by the CPU-only generator"

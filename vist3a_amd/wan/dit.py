@@ -318,12 +318,16 @@ class WanDiT:
     @torch.no_grad()
     def forward(self, hidden_states: Optional[torch.Tensor], timestep, encoder_hidden_states: torch.Tensor,
                 return_dict: bool = False, num_layers: Optional[int] = None, sp=None, tokens_in: bool = False, tokens_out: bool = False,
-                latent_shape: Optional[tuple] = None, time_table: Optional[tuple] = None):
+                latent_shape: Optional[tuple] = None, time_table: Optional[tuple] = None, hidden_in: Optional[torch.Tensor] = None,
+                first_layer: int = 0, return_hidden: bool = False):
         """`sp` (wan/seqpar.py group) shards the latent tokens over sp.world ranks: every rank passes the SAME full
         `hidden_states` and gets the full prediction back; only N/P token rows are computed locally.
         Fused denoise loop (wan/pipeline.py): `tokens_in` = the patchified input already sits in `token_buffers()[0]` (written by
         ops.unipc_cfg_step; `hidden_states` may be None, `latent_shape` gives [B, C, T, H, W]); `tokens_out` = return the raw output
-        tokens (`token_buffers()[1]`) instead of the un-patchified tensor; `time_table` = this step's (temb, mod) from `time_tables()`."""
+        tokens (`token_buffers()[1]`) instead of the un-patchified tensor; `time_table` = this step's (temb, mod) from `time_tables()`.
+        Teacher forcing (tests): `hidden_in` [B, N, d] replaces the residual stream in front of block `first_layer`, blocks
+        first_layer .. num_layers - 1 run, and `return_hidden` returns the residual stream behind the last of them ([B, N, d] bf16 copy)
+        instead of the prediction (single GPU only)."""
         cfg = self.cfg
         B, C, Fr, Hh, Ww = hidden_states.shape if hidden_states is not None else latent_shape
         pt, ph, pw = cfg.patch_size
@@ -363,6 +367,11 @@ class WanDiT:
 
         nl = cfg.num_layers if num_layers is None else num_layers
         Ml = B * Nl
+        if hidden_in is not None or return_hidden or first_layer:
+            if P != 1:
+                raise ValueError("hidden_in / first_layer / return_hidden: single GPU only")
+            if hidden_in is not None:
+                x.copy_(hidden_in.reshape(x.shape))
         if P == 1:
             q, k = ws.qk[:, :d], ws.qk[:, d:]
             vbs = ws.vt.shape[1] // B
@@ -394,7 +403,7 @@ class WanDiT:
             else:
                 ops.layernorm(x, out=ws.n, eps=cfg.eps, **kw)
 
-        for li in range(nl):
+        for li in range(first_layer, nl):
             b, m = self.blocks[li], mod[li]
             # --- self attention
             norm(scale=m[:, 1], shift=m[:, 0], rows_per_batch=Nl)
@@ -511,6 +520,8 @@ class WanDiT:
             else:
                 lin(ws.h, b, "w2", b["b2"], out=x, residual=x, scale=m[:, 5], rows_per_batch=Nl)
 
+        if return_hidden:
+            return x.view(B, Nl, d).clone()
         om = (self.out_sst[None] + temb.float()[:, None]).contiguous()  # [B,2,d]
         ops.layernorm(x, out=ws.n, scale=om[:, 1], shift=om[:, 0], rows_per_batch=Nl, eps=cfg.eps)
         ops.gemm(ws.n, self.po_w, self.po_b, out=ws.out)

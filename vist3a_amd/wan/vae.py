@@ -147,6 +147,22 @@ class WanVAEDecoder:
         video = y[..., :3].permute(3, 0, 1, 2).unsqueeze(0).contiguous()
         return video if return_dict else (video,)
 
+    @staticmethod
+    def _upsample(x: torch.Tensor, mode: str, rs, tc) -> torch.Tensor:
+        """WanResample upsample2d / upsample3d (wan_utils.py:202-330) on a channels-last clip [T,H,W,C]"""
+        T = x.shape[0]
+        if mode == "upsample3d" and T > 1:
+            # time_conv emits 2C channels per frame t >= 1: the first C are frame 2t-1, the last C frame 2t of the doubled clip.  Two
+            # convolutions over the halves of the output channels write those frames in place (row scatter of the GEMM epilogue:
+            # pixel m of frame t-1 -> frame 1 + 2(t-1) + half) instead of one convolution plus two strided interleave copies.
+            HW = x.shape[1] * x.shape[2]
+            y = torch.empty((1 + 2 * (T - 1), *x.shape[1:]), device=x.device, dtype=bf16)
+            y[0] = x[0]
+            for half, tch in enumerate(tc):
+                ops.conv(x[1:], tch, pad=(2, 0, 0), out=y, out_rows=(HW, HW, (1 + half) * HW))
+            x = y
+        return ops.conv(x, rs, pad=(0, 1, 1), ups2=True)
+
     @torch.no_grad()
     def decode_cl(self, z: torch.Tensor) -> torch.Tensor:
         """Same decode, result left channels-last [T, 8h, 8w, 8] bf16 (RGB in channels 0-2, clamped to [-1,1]) — the layout
@@ -164,18 +180,7 @@ class WanVAEDecoder:
                 x = r(x)
             if mode is None:
                 continue
-            T = x.shape[0]
-            if mode == "upsample3d" and T > 1:
-                # time_conv emits 2C channels per frame t >= 1: the first C are frame 2t-1, the last C frame 2t of the doubled clip.  Two
-                # convolutions over the halves of the output channels write those frames in place (row scatter of the GEMM epilogue:
-                # pixel m of frame t-1 -> frame 1 + 2(t-1) + half) instead of one convolution plus two strided interleave copies.
-                HW = x.shape[1] * x.shape[2]
-                y = torch.empty((1 + 2 * (T - 1), *x.shape[1:]), device=x.device, dtype=bf16)
-                y[0] = x[0]
-                for half, tch in enumerate(tc):
-                    ops.conv(x[1:], tch, pad=(2, 0, 0), out=y, out_rows=(HW, HW, (1 + half) * HW))
-                x = y
-            x = ops.conv(x, rs, pad=(0, 1, 1), ups2=True)
+            x = self._upsample(x, mode, rs, tc)
         n = ops.rownorm_act(x, self.g_out, mode=1, act=L.ACT_SILU)
         y = ops.conv(n, self.conv_out, pad=(2, 1, 1))  # [T,H,W,8] (3 real channels, 5 zero)
         return y.clamp_(-1.0, 1.0)
