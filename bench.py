@@ -233,6 +233,7 @@ def main():
     if coop:
         from vist3a_amd.wan.seqpar import DenoisePlan
         model.pipe.plan = DenoisePlan.from_dist()
+        model.stitched_decoder.recon_group = model.pipe.plan.world      # reconstruction split by views over all ranks of the scene
         if a.sp_graph:
             from vist3a_amd.wan.dit import GraphedWanDiT
             model.pipe.transformer = GraphedWanDiT(model.transformer, capture_sp=True)
@@ -287,6 +288,15 @@ def main():
         dist.all_gather_into_tensor(allr.view(-1), mine)
         per_rank = [{"rank": r, "wall_s": round(v[0], 3), "denoise_ms": round(v[1], 1), "vae_ms": round(v[2], 1), "recon_ms": round(v[3], 1)}
                     for r, v in enumerate(allr.cpu().tolist())]
+        if coop:   # the view-sharded reconstruction of the last scene, stage by stage, on every rank (the Amdahl term of the latency mode)
+            st = getattr(model.stitched_decoder, "recon_shard_times", None) or {}
+            mine = torch.tensor([st.get("views", [0, 0])[0], st.get("backbone_ms", 0.0), st.get("camera_ms", 0.0), st.get("heads_ms", 0.0),
+                                 st.get("gather_and_tail_ms", 0.0)], device=dev, dtype=torch.float64)
+            allr = torch.empty(world, 5, device=dev, dtype=torch.float64)
+            dist.all_gather_into_tensor(allr.view(-1), mine)
+            for pr, v in zip(per_rank, allr.cpu().tolist()):
+                pr["recon_view_shard"] = {"views": int(v[0]), "backbone_ms": round(v[1], 1), "camera_replicated_ms": round(v[2], 1),
+                                          "heads_ms": round(v[3], 1), "gather_and_tail_ms": round(v[4], 1)}
         dt = tt.item()
     comm = None
     if coop:

@@ -81,6 +81,7 @@ def main(args):
     if coop:  # every rank works on the same prompt: CFG-parallel x sequence-parallel denoise, rank 0 writes
         from vist3a_amd.wan.seqpar import DenoisePlan
         scene.pipe.plan = DenoisePlan.from_dist()
+        stitched.recon_group = scene.pipe.plan.world      # the reconstruction of the scene split by views over the same ranks
     embeds = torch.load(args.text_embeds_path, map_location="cpu") if args.text_embeds_path else None
     encode = None if (embeds is not None or args.synthetic_text) else build_text_encoder(args, device)
     for prompt in prompts:

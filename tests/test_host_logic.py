@@ -412,3 +412,71 @@ def test_committed_oracle_digests_match_the_current_oracle_sources():
         name = f.stem[len("oracle_"):]
         assert meta.get("oracle_sources_sha256") == OC.source_hash(FC.SOURCES[name]), f"{f.name} is stale: re-run tests/golden/make_fullsize_oracle.py"
         assert meta.get("generated_without_gpu") == "True", f"{f.name} was not written by the CPU-only generator"
+
+
+_VIEW_SHARD_WORKER = '''
+import sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from vist3a_amd.utils.dist_util import setup_dist
+from vist3a_amd.wan.seqpar import DenoisePlan
+from vist3a_amd.recon.engine import ReconEngine as E, OUT_COLS
+setup_dist("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+plan = DenoisePlan.from_dist()
+grp = plan.world
+ok = grp is not None and grp.world == 2 and grp.rank == r
+S, Pp, C = 13, 16, 8
+views = E.shard_views(S, w)
+ok = ok and views == [(0, 7), (7, 13)]
+v0, v1 = views[r]
+Sl, maxS = v1 - v0, 7
+Mx = maxS * Pp
+# a global block's exchange: every rank contributes the K rows / V^T columns of ITS views, everybody reassembles all 13 views in order
+K = torch.arange(S * Pp * C, dtype=torch.float32).view(S * Pp, C)
+Vt = -torch.arange(C * S * Pp, dtype=torch.float32).view(C, S * Pp)
+pack, gbuf = torch.zeros(2 * Mx * C), torch.zeros(w, 2 * Mx * C)
+E.kv_pack(pack, K[v0 * Pp: v1 * Pp], Vt[:, v0 * Pp: v1 * Pp], Mx)
+grp.all_gather(gbuf, pack).wait()
+kf, vtf = torch.zeros(S * Pp, C), torch.zeros(C, S * Pp + 64)
+E.kv_unpack(gbuf, views, Pp, Mx, kf, vtf)
+ok = ok and torch.equal(kf, K) and torch.equal(vtf[:, : S * Pp], Vt) and bool((vtf[:, S * Pp:] == 0).all())
+# camera-token rows and the per-pixel maps: padded per-rank blocks -> rows of all views in view order
+HW = 6
+full = torch.arange(S * HW * OUT_COLS, dtype=torch.float32).view(S * HW, OUT_COLS)
+op, og = torch.zeros(maxS * HW * OUT_COLS), torch.zeros(w, maxS * HW * OUT_COLS)
+op.view(maxS * HW, OUT_COLS)[: Sl * HW] = full[v0 * HW: v1 * HW]
+grp.all_gather(og, op).wait()
+ok = ok and torch.equal(E.gather_rows(og, views, HW, OUT_COLS, maxS), full)
+res = [None] * w
+dist.all_gather_object(res, bool(ok))
+if r == 0:
+    print(json.dumps(res))
+dist.destroy_process_group()
+'''
+
+
+def test_view_sharded_reconstruction_exchange_world_size_2_gloo(tmp_path):
+    """SURVEY 8(e) "Recon under SP": the 13 -> 7 / 6 view split of `ReconEngine.forward_sharded` over two real processes (gloo): the
+    DenoisePlan's world group, the K | V^T pack / all-gather / reassembly of a global block and the final per-pixel gather, through the
+    very helpers the GPU path calls (kv_pack / kv_unpack / gather_rows) - ragged shards included."""
+    script = tmp_path / "vs.py"
+    script.write_text(_VIEW_SHARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", str(script), str(ROOT)], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    line = [l for l in r.stdout.splitlines() if l.startswith("[")][-1]
+    assert json.loads(line) == [True, True]
+
+
+def test_shard_views_layout():
+    from vist3a_amd.recon.engine import ReconEngine as E
+    for S in (1, 5, 13, 21):
+        for w in (1, 2, 3, 4, 8):
+            v = E.shard_views(S, w)
+            assert len(v) == w and v[0][0] == 0 and v[-1][1] == S and all(a[1] == b[0] for a, b in zip(v, v[1:]))
+            sizes = [b - a for a, b in v]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert E.shard_views(13, 4) == [(0, 4), (4, 7), (7, 10), (10, 13)] and E.shard_views(21, 8)[0] == (0, 3)

@@ -314,3 +314,79 @@ def test_batched_forward_assembles_scenes_like_the_reference(hip_lib):
         assert torch.allclose(out.pred_context_pose["extrinsic"][b], singles[b]["ext"][0], atol=1e-6, rtol=1e-6)   # (batched 4x4 inverse)
     assert anchor.shape[:2] == (2, img.shape[2]) and conf.shape == dconf.shape == out.depth_dict["conf_valid_mask"].shape
     assert abs(out.infos["scene_scale"].item() - 0.5 * (singles[0]["scale"].item() + singles[1]["scale"].item())) < 1e-5 * out.infos["scene_scale"].item()
+
+
+def _stitched_model(sd, rcfg_kw, C):
+    from vist3a_amd.models.anysplat_stitched import AnySplatWeights
+    from vist3a_amd.models.stitched_model import StitchVAE3D
+    from vist3a_amd.models.stitching_layer_builder import parse_conv_spec
+    from vist3a_amd.recon.engine import ReconCfg
+    return StitchVAE3D(None, AnySplatWeights(dict(sd), ReconCfg(**rcfg_kw)), "cuda", "enc_blocks_2",
+                       parse_conv_spec(f"conv3d_k5x3x3_o{C}_s1x2x2_p2x1x1"), resolution=512)
+
+
+def _sharded_vs_unsharded(model, lat, img, worlds):
+    """forward_with_latent over P virtual ranks (threads on this GPU, seqpar.ThreadWorld) vs the plain forward: every output bit for bit"""
+    from vist3a_amd.wan.seqpar import ThreadWorld
+    raw = {}
+    real_package = model.stitched_3d_model.package
+
+    def spy(out, *a, **k):
+        raw[__import__("threading").get_ident()] = {kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in out.items() if kk in
+                                                    ("depth", "depth_conf", "pts_all", "raw_gs", "voxel_keys", "voxel_inverse", "voxel_counts")}
+        return real_package(out, *a, **k)
+    model.stitched_3d_model.package = spy
+    try:
+        model.recon_group = None
+        ref = model.forward_with_latent(lat, img, train=False)
+        ref_raw = raw.pop(__import__("threading").get_ident())
+        for P in worlds:
+            w = ThreadWorld(P)
+
+            def run(r):
+                import threading
+                o = model.forward_with_latent(lat, img, train=False, recon_group=w.group(r))   # the ranks share the engine: workspaces are per thread
+                return o, raw[threading.get_ident()]
+            outs = w.run(run)
+            torch.cuda.synchronize()
+            for o, rr in outs:
+                for k in ("means", "covariances", "harmonics", "opacities", "scales", "rotations"):
+                    assert torch.equal(getattr(o.gaussians, k), getattr(ref.gaussians, k)), (P, k)
+                assert torch.equal(o.depth_dict["depth"], ref.depth_dict["depth"]) and torch.equal(o.pred_pose_enc_list[-1], ref.pred_pose_enc_list[-1])
+                for k, v in ref_raw.items():
+                    assert torch.equal(rr[k], v), (P, k)
+    finally:
+        model.stitched_3d_model.package = real_package
+    return ref
+
+
+def test_view_sharded_forward_is_bit_identical(hip_lib):
+    """the reconstruction of one scene split by VIEWS over the ranks of a scene-parallel run (`ReconEngine.forward_sharded`:
+    per-view DINO / frame blocks / DPT heads, one K | V^T all-gather per global block, replicated camera head and voxel tail) equals the
+    unsharded forward bit for bit - width 128 / 2 heads, 5 views @ 448 x 448 (1029 tokens per view: the padded-row key mask, halo-form DPT
+    convolutions) over 2, 4 and 8 ranks (ragged 3 / 2, 2 / 1 / 1 / 1, and ranks WITHOUT a view)."""
+    RECON_MH = dict(C=128, heads=2, n_dino=22, depth=24, cam_heads=4, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+    sd = R.make_recon_weights(R.ReconCfg(**RECON_MH), seed=43)
+    model = _stitched_model(sd, RECON_MH, 128)
+    g = torch.Generator().manual_seed(91)
+    model.stitching_layer.weight.data = torch.randn(128, 16, 5, 3, 3, generator=g) * 0.08
+    model.stitching_layer.bias.data = torch.randn(128, generator=g) * 0.1
+    lat = torch.randn(1, 16, 2, 64, 64, generator=g).cuda()
+    img = (torch.rand(1, 3, 5, 448, 448, generator=g) * 2 - 1).cuda()
+    _sharded_vs_unsharded(model, lat, img, (2, 4, 8))
+
+
+def test_view_sharded_forward_production_width_21_views(hip_lib, parity):
+    """BASELINE config #3's reconstruction (21 views @448, width 1024, 16 heads x 64) over 4 virtual ranks (6 / 5 / 5 / 5 views):
+    bit-identical to the unsharded forward, with the per-stage times of one rank's share."""
+    from vist3a_amd.recon.engine import ReconCfg
+    from vist3a_amd.recon.weights import random_recon_state_dict, round_aggregator_to_bf16
+    sd = round_aggregator_to_bf16(random_recon_state_dict(ReconCfg(), seed=5, device="cuda", scene_like=True))
+    model = _stitched_model(sd, {}, 1024)
+    g = torch.Generator().manual_seed(92)
+    model.stitching_layer.weight.data = torch.randn(1024, 16, 5, 3, 3, generator=g) * 0.02
+    model.stitching_layer.bias.data = torch.randn(1024, generator=g) * 0.02
+    lat = torch.randn(1, 16, 6, 64, 64, generator=g).cuda()
+    img = (torch.rand(1, 3, 21, 448, 448, generator=g) * 2 - 1).cuda()
+    ref = _sharded_vs_unsharded(model, lat, img, (4,))
+    parity("recon_view_sharded_S21_C1024_P4", gaussians=ref.gaussians.means.shape[1], bit_identical=True, shard_times_ms=dict(model.recon_shard_times))

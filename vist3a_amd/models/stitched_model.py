@@ -69,9 +69,14 @@ class StitchVAE3D(torch.nn.Module):
         return self.forward_with_latent(latent, feedforward_image, train=train)
 
     @torch.no_grad()
-    def forward_with_latent(self, latent: torch.Tensor, feedforward_image: torch.Tensor, train: bool = False, image_cl: Optional[torch.Tensor] = None):
+    def forward_with_latent(self, latent: torch.Tensor, feedforward_image: torch.Tensor, train: bool = False, image_cl: Optional[torch.Tensor] = None,
+                            recon_group=None):
         """latent: de-normalised VAE latent [B,16,Tl,64,64]; feedforward_image [B,3,T,448,448] in [-1,1]
-        (or, MI355X fast path, image_cl [T,448,448,8] in [-1,1] as produced by WanVAEDecoder.decode_cl + resize; [B,T,448,448,8] for B > 1)."""
+        (or, MI355X fast path, image_cl [T,448,448,8] in [-1,1] as produced by WanVAEDecoder.decode_cl + resize; [B,T,448,448,8] for B > 1).
+        recon_group (default: the attribute `self.recon_group`, None = this GPU alone): the ranks of a scene-parallel run (seqpar DistGroup /
+        ThreadGroup) - every rank calls with the SAME inputs, the reconstruction is split by views (ReconEngine.forward_sharded) and every rank
+        gets the whole scene back."""
+        grp = recon_group if recon_group is not None else getattr(self, "recon_group", None)
         if latent.shape[0] != 1:
             # b > 1 (stitched_model.py:165-173 is batch-agnostic): every scene goes through exactly the b = 1 path below - stitching conv
             # writing tokens in place, one engine forward - and the reference's batch assembly follows (AnySplatStitched.assemble_batch)
@@ -84,13 +89,13 @@ class StitchVAE3D(torch.nn.Module):
             outs, shp = [], None
             for b in range(B):
                 o, shp = self._scene(latent[b:b + 1], None if feedforward_image is None else feedforward_image[b:b + 1],
-                                     None if image_cl is None else image_cl[b])
+                                     None if image_cl is None else image_cl[b], grp)
                 outs.append(model.keep_scene(o))
             return model.assemble_batch(outs, *shp, train)
-        out, (S, H, W) = self._scene(latent, feedforward_image, image_cl)
+        out, (S, H, W) = self._scene(latent, feedforward_image, image_cl, grp)
         return self.stitched_3d_model.package(out, S, H, W, train)
 
-    def _scene(self, latent: torch.Tensor, feedforward_image: Optional[torch.Tensor], image_cl: Optional[torch.Tensor]):
+    def _scene(self, latent: torch.Tensor, feedforward_image: Optional[torch.Tensor], image_cl: Optional[torch.Tensor], grp=None):
         """one scene: T-upsample -> stitching conv into the token workspace -> reconstruction engine; -> (raw engine outputs, (S, H, W))"""
         st = self.stitching_layer
         eng = self.stitched_3d_model.engine()
@@ -111,6 +116,16 @@ class StitchVAE3D(torch.nn.Module):
         oshape = [(lat_cl.shape[i] + 2 * st.padding3[i] - st.kernel3[i]) // st.stride3[i] + 1 for i in range(3)]
         if oshape[0] != S or oshape[1] * oshape[2] != hw or cw.CoutP != eng.cfg.C:
             raise ValueError(f"stitching layer output {oshape}x{cw.Cout} does not match the {S}x{g['hp']}x{g['wp']}x{eng.cfg.C} token grid")
+        if grp is not None and grp.world > 1:
+            # one scene over several ranks (scene-parallel latency mode): the stitching convolution (2e10 FLOP) runs on every rank into a
+            # private token buffer, the reconstruction is split by views (ReconEngine.forward_sharded)
+            import threading
+            x = eng.token_buffer(S, H, W, threading.get_ident())
         ops.conv(lat_cl, cw, out=x, stride=st.stride3, pad=st.padding3, out_size=tuple(oshape), replicate=True,
                  residual=g["pos_patch"], res_row_mod=hw, out_rows=(hw, Pp - hw, nsp))
+        if grp is not None and grp.world > 1:
+            times = {}
+            out = eng.forward_sharded(S, H, W, x, img01.contiguous(), grp, timings=times)
+            self.recon_shard_times = times      # (last scene, this rank)
+            return out, (S, H, W)
         return eng.forward_tokens_filled(S, H, W, img01.contiguous()), (S, H, W)

@@ -443,12 +443,16 @@ def conv_split(
     x: torch.Tensor, cw: ConvWeightSplit, *, out: Optional[torch.Tensor] = None, stride=(1, 1, 1), pad=(0, 0, 0), out_size=None,
     act: int = L.ACT_NONE, residual: Optional[torch.Tensor] = None, out_f32: bool = False, tile: int = -1,
     residual2: Optional[torch.Tensor] = None, res_row_mod: int = 0, relu_out: bool = False, out_rows: Optional[tuple] = None,
+    form_frames: Optional[int] = None,
 ) -> torch.Tensor:
     """fp32-equivalent convolution (v3a_conv_split).  x: pair [2,T,H,W,CinP] -> pair [2,oT,oH,oW,CoutP] (or f32 [oT,oH,oW,CoutP] with
     out_f32).  residual: an f32 tensor (table; res_row_mod as in `conv`) or a pair; residual2: a pair.  No bf16 rounding anywhere between
     the accumulator and the store; geometry arguments as in `conv`.
     tile: -1 = automatic (the halo-tile form for wide 3x3 layers, else the implicit GEMM with a heuristic tile), >= 0 = that implicit-GEMM
-    tile, -2 = force the halo-tile form, -3 = never the halo-tile form."""
+    tile, -2 = force the halo-tile form, -3 = never the halo-tile form.
+    form_frames (with tile = -1): choose between the two forms as if the clip had this many frames - a rank that holds a few views of a
+    scene takes the form the whole scene would take, so view-sharded results stay bit-identical to the unsharded ones (the two forms
+    differ in fp32 summation order)."""
     if x.dim() != 5 or x.shape[0] != 2 or not x.is_contiguous() or x.dtype != bf16 or not x.is_cuda:
         raise ValueError("x must be a contiguous device bf16 pair [2,T,H,W,C]")
     _, T, H, W, Cin = x.shape
@@ -503,6 +507,9 @@ def conv_split(
         _ptr(cw.w_halo), 1 if cw.w_halo is not None else 0,
     )
     args = L.ConvSplitArgs(cargs, _ptr(x[1]), _ptr(o_lo), _ptr(r_lo), _ptr(q_lo))
+    if form_frames is not None and tile == -1 and cw.w_halo is not None:
+        per_frame = L.load().v3a_conv_split_halo_tiles(C.byref(args)) // T          # 0: the layer has no halo form
+        args.c.tile = -2 if per_frame * form_frames >= 128 else -3
     L.check(L.load().v3a_conv_split(C.byref(args), _stream()), "v3a_conv_split")
     return out
 

@@ -191,8 +191,9 @@ class ReconEngine:
         self._geo: Dict[tuple, dict] = {}
 
     # ------------------------------------------------------------------ per-resolution constants / workspaces
-    def _geometry(self, S, H, W):
-        key = (S, H, W)
+    def _geometry(self, S, H, W, tag=None):
+        """workspaces + per-resolution constants for S views; `tag` separates the workspaces of virtual ranks (threads) sharing this engine"""
+        key = (S, H, W) if tag is None else (S, H, W, tag)
         g = self._geo.get(key)
         if g is not None:
             return g
@@ -220,7 +221,7 @@ class ReconEngine:
         return g
 
     # ------------------------------------------------------------------ transformer blocks
-    def _attn(self, g, blk, S, glob: bool, rope: bool):
+    def _attn(self, g, blk, S, glob: bool, rope: bool, shard=None):
         cfg = self.cfg
         C, H, P, Pp, M = cfg.C, cfg.heads, g["P"], g["Pp"], g["M"]
         ops.gemm(g["n"], blk.wqk, blk.bqk, out=g["qk"])
@@ -228,28 +229,41 @@ class ReconEngine:
         if rope:
             ops.qknorm_rope2d(g["qk"], C, blk.qw, blk.qb, blk.kw, blk.kb, g["rope"], Pp, g["nsp"], P, g["wp"], 1e-5)
         q, k = g["qk"][:, :C], g["qk"][:, C:]
-        if glob:
+        if glob and shard is not None:
+            # view-sharded global attention (aggregator.py:347-373 attends over the tokens of ALL views): this rank's K rows and V^T columns
+            # go out in ONE all-gather per block, every rank reassembles the full [S Pp, C] K and [C, S Pp] V^T in view order, and the local
+            # views' queries walk all keys - the same keys in the same order through the same kernel as the unsharded launch: bit-identical
+            sh = shard
+            Mx = sh["maxS"] * Pp
+            pack, gbuf, kf, vtf = sh["pack"], sh["gbuf"], sh["kfull"], sh["vtfull"]
+            self.kv_pack(pack, k, g["vt"][:, :M], Mx)
+            sh["group"].all_gather(gbuf, pack).wait()
+            self.kv_unpack(gbuf, sh["views"], Pp, Mx, kf, vtf)
+            Mt = sh["S"] * Pp
+            ops.attention(q, kf, vtf, g["ao"], B=1, H=H, Nq=M, Nk=Mt, D=C // H, q_batch_stride=0, k_batch_stride=0,
+                          vt_batch_stride=0, o_batch_stride=0, kv_period=Pp if Pp != P else 0, kv_valid=P)
+        elif glob:
             ops.attention(q, k, g["vt"], g["ao"], B=1, H=H, Nq=M, Nk=M, D=C // H, q_batch_stride=0, k_batch_stride=0,
                           vt_batch_stride=0, o_batch_stride=0, kv_period=Pp if Pp != P else 0, kv_valid=P)
         else:
             ops.attention(q, k, g["vt"], g["ao"], B=S, H=H, Nq=P, Nk=P, D=C // H, q_batch_stride=Pp * 2 * C,
                           k_batch_stride=Pp * 2 * C, vt_batch_stride=Pp, o_batch_stride=Pp * C)
 
-    def _block(self, g, blk, x, S, glob, rope, eps, xo=None):
+    def _block(self, g, blk, x, S, glob, rope, eps, xo=None, shard=None):
         """x: residual stream (bf16 for DINO, f32 for the aggregator).  The block's output goes to `xo` (default: x, in place); with
         xo != x the attention branch already lands in xo (residual read from x), so x is left untouched - how the tapped aggregator
         blocks write their output straight into the [M, 2C] tap buffers (row stride 2C) instead of being copied there afterwards."""
         f = x.dtype == f32
         xo = x if xo is None else xo
         ops.layernorm(x, out=g["n"], weight=blk.n1w, bias=blk.n1b, eps=eps)
-        self._attn(g, blk, S, glob, rope)
+        self._attn(g, blk, S, glob, rope, shard)
         ops.gemm(g["ao"], blk.wo, blk.bo, out=xo, residual=x, scale=blk.ls1, round_after_scale=True, out_f32=f)
         ops.layernorm(xo, out=g["n"], weight=blk.n2w, bias=blk.n2b, eps=eps)
         ops.gemm(g["n"], blk.w1, blk.b1, out=g["h"], act=L.ACT_GELU_ERF)
         ops.gemm(g["h"], blk.w2, blk.b2, out=xo, residual=xo, scale=blk.ls2, round_after_scale=True, out_f32=f)
 
-    def backbone(self, g, S):
-        """x (bf16 tokens incl. DINO specials) -> tapped [M, 2C] f32 intermediates."""
+    def backbone(self, g, S, shard=None):
+        """x (bf16 tokens incl. DINO specials) -> tapped [M, 2C] f32 intermediates.  `shard` (forward_sharded): S = this rank's views."""
         cfg = self.cfg
         C, Pp, nsp = cfg.C, g["Pp"], g["nsp"]
         x, xf = g["x"], g["xf"]
@@ -257,7 +271,7 @@ class ReconEngine:
         for blk in self.dino:
             self._block(g, blk, x, S, False, False, 1e-6)
         ops.layernorm(x, out=xf, weight=self.dino_nw, bias=self.dino_nb, eps=1e-6)
-        xf.view(S, Pp, C)[:, :nsp] = g["special_agg"]
+        xf.view(S, Pp, C)[:, :nsp] = g["special_agg"] if shard is None else shard["special_agg"]
         # The residual stream walks THROUGH the tap buffers (anysplat_stitched.py:249-325 concatenates the frame and global intermediates
         # of the tapped layers): a tapped frame block writes its output into the left half of the tap, the global block reads it there
         # and writes the right half, the next frame block reads that and returns to xf.  No concatenation copies (8 x 55 MB per scene).
@@ -268,16 +282,17 @@ class ReconEngine:
             self._block(g, self.frame[li], cur, S, False, True, 1e-5, xo=dst)
             cur = dst
             dst = g["taps"][ti][:, C:] if tap else xf
-            self._block(g, self.glob[li], cur, S, True, True, 1e-5, xo=dst)
+            self._block(g, self.glob[li], cur, S, True, True, 1e-5, xo=dst, shard=shard)
             cur = dst
             ti += int(tap)
         return g["taps"]
 
     # ------------------------------------------------------------------ camera head (fp32)
-    def camera(self, g, S, iters: int = 4) -> List[torch.Tensor]:
+    def camera(self, g, S, iters: int = 4, pose_tokens: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+        """pose_tokens [S, 2C] f32: the camera-token rows of the last tap (default: read from this workspace's taps)"""
         cfg, cam = self.cfg, self.cam
         C2, Hh = 2 * cfg.C, cfg.cam_heads
-        pt = g["taps"][-1].view(S, g["Pp"], C2)[:, 0].contiguous()
+        pt = g["taps"][-1].view(S, g["Pp"], C2)[:, 0].contiguous() if pose_tokens is None else pose_tokens.contiguous()
         pt = ops.layernorm(pt, weight=cam["token_norm.weight"], bias=cam["token_norm.bias"], eps=1e-5, out_dtype=f32)
         pred, outs = None, []
         for _ in range(iters):
@@ -344,51 +359,55 @@ class ReconEngine:
         hp, wp, hw, Pp, nsp = g["hp"], g["wp"], g["hw"], g["Pp"], g["nsp"]
         C2 = 2 * cfg.C
         lv = []
+        ff = g.get("form_frames")       # view-sharded forward: kernel-form decisions follow the scene's frame count, not the shard's
+        cs = lambda x_, cw_, **kw: ops.conv_split(x_, cw_, form_frames=ff, **kw)
         for i, tap in enumerate(g["taps"]):
             n = ops.layernorm_pair(tap, weight=hd.nw, bias=hd.nb, eps=1e-5, M=S * hw, in_rows=(hw, Pp - hw, nsp)).view(2, S, hp, wp, C2)
-            x = ops.conv_split(n, hd.proj[i], residual=hd.pos(hd.proj[i].CoutP, hp, wp, W, H, dev), res_row_mod=hw)
+            x = cs(n, hd.proj[i], residual=hd.pos(hd.proj[i].CoutP, hp, wp, W, H, dev), res_row_mod=hw)
             if i < 2:
                 per_dy, k, co = hd.up[i]
                 up = torch.empty(2, S, hp * k, wp, k * co, device=dev, dtype=bf16)
                 for dy, cwt in enumerate(per_dy):
-                    ops.conv_split(x, cwt, out=up, out_rows=(wp, (k - 1) * wp, dy * wp))
+                    cs(x, cwt, out=up, out_rows=(wp, (k - 1) * wp, dy * wp))
                 x = up.view(2, S, hp * k, wp * k, co)
             elif i == 3:
-                x = ops.conv_split(x, hd.down, stride=(1, 2, 2), pad=(0, 1, 1))
-            lv.append(ops.conv_split(x, hd.rn[i], pad=(0, 1, 1), relu_out=True))
+                x = cs(x, hd.down, stride=(1, 2, 2), pad=(0, 1, 1))
+            lv.append(cs(x, hd.rn[i], pad=(0, 1, 1), relu_out=True))
         R = L.ACT_RELU
 
         def rcu2_out(f, s, size):
-            c1 = ops.conv_split(s, f["c21"], pad=(0, 1, 1), act=R)
-            o = ops.conv_split(c1, f["c22"], pad=(0, 1, 1), residual=s)
-            o = ops.conv_split(o, f["out"])
+            c1 = cs(s, f["c21"], pad=(0, 1, 1), act=R)
+            o = cs(c1, f["c22"], pad=(0, 1, 1), residual=s)
+            o = cs(o, f["out"])
             return ops.bilinear_cl_pair(o, size, align_corners=True)
 
         o = rcu2_out(hd.fus[4], lv[3], lv[2].shape[2:4])
         for r, l in ((3, lv[2]), (2, lv[1]), (1, lv[0])):
             f = hd.fus[r]
-            c1 = ops.conv_split(l, f["c11"], pad=(0, 1, 1), act=R)
-            s = ops.conv_split(c1, f["c12"], pad=(0, 1, 1), residual=l, residual2=o, relu_out=True)
+            c1 = cs(l, f["c11"], pad=(0, 1, 1), act=R)
+            s = cs(c1, f["c12"], pad=(0, 1, 1), residual=l, residual2=o, relu_out=True)
             size = lv[r - 2].shape[2:4] if r > 1 else (l.shape[2] * 2, l.shape[3] * 2)
             o = rcu2_out(f, s, size)
-        return ops.conv_split(o, hd.oc1, pad=(0, 1, 1))
+        return cs(o, hd.oc1, pad=(0, 1, 1))
 
     def _heads_f32(self, g, S, H, W, img: torch.Tensor, cam: torch.Tensor):
         """img: [S,H,W,8] f32 (3 real channels, in [0,1])."""
         dev = self.dev
         R = L.ACT_RELU
+        ff = g.get("form_frames")
+        cs = lambda x_, cw_, **kw: ops.conv_split(x_, cw_, form_frames=ff, **kw)
         d = self.depth_head
         o = self._dpt_trunk_f32(g, d, S, H, W)
         up = ops.bilinear_cl_pair(o, (H, W), align_corners=True, table=d.pos(o.shape[-1], H, W, W, H, dev))
-        c = ops.conv_split(up, d.oc20, pad=(0, 1, 1), act=R)
-        raw = ops.conv_split(c, d.oc22, out_f32=True).view(S * H * W, -1)
+        c = cs(up, d.oc20, pad=(0, 1, 1), act=R)
+        raw = cs(c, d.oc22, out_f32=True).view(S * H * W, -1)
         depth, dconf, pts = ops.depth_unproject(raw, cam, S, H, W)
         q = self.gs_head
         o = self._dpt_trunk_f32(g, q, S, H, W)
-        di = ops.conv_split(ops.split_f32(img), q.merger, pad=(0, 3, 3), act=R)
+        di = cs(ops.split_f32(img), q.merger, pad=(0, 3, 3), act=R)
         up = ops.bilinear_cl_pair(o, (H, W), align_corners=True, add=di, table=q.pos(o.shape[-1], H, W, W, H, dev))
-        c = ops.conv_split(up, q.oc20, pad=(0, 1, 1), act=R)
-        raw_gs = ops.conv_split(c, q.oc22, out_f32=True).view(S * H * W, -1)
+        c = cs(up, q.oc20, pad=(0, 1, 1), act=R)
+        raw_gs = cs(c, q.oc22, out_f32=True).view(S * H * W, -1)
         return depth, dconf, pts, raw_gs
 
     def heads(self, g, S, H, W, img_cl: torch.Tensor, pose: torch.Tensor):
@@ -429,6 +448,11 @@ class ReconEngine:
         self.backbone(g, S)
         poses = self.camera(g, S)
         depth, dconf, pts, raw_gs, ext, K = self.heads(g, S, H, W, img_cl, poses[-1])
+        return self._tail(S, H, W, poses, depth, dconf, pts, raw_gs, ext, K)
+
+    def _tail(self, S, H, W, poses, depth, dconf, pts, raw_gs, ext, K) -> dict:
+        """per-pixel maps of all S views -> confidence mask / voxel fusion / Gaussian adapter (anysplat_stitched.py:381-453)"""
+        cfg = self.cfg
         gsd = 1 + 7 + 3 * (cfg.sh_degree + 1) ** 2  # 83: density + raw gaussian; confidence sits in the next column
         out = dict(pred_pose_enc_list=poses, depth=depth, depth_conf=dconf, pts_all=pts, raw_gs=raw_gs, extrinsic_w2c=ext, intrinsic_px=K)
         M = S * H * W
@@ -452,6 +476,119 @@ class ReconEngine:
         out["num_points"] = M
         return out
 
+    # ------------------------------------------------------------------ view-sharded forward (one scene over several ranks)
+    @staticmethod
+    def kv_pack(pack: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, Mx: int) -> None:
+        """a rank's contribution to a global block's all-gather: [K rows [M, C] | V^T [C, Mx] (M valid columns)] in one flat buffer"""
+        M, C = k.shape
+        pack[: M * C].view(M, C).copy_(k)
+        pack[Mx * C:].view(C, Mx)[:, :M].copy_(vt)
+
+    @staticmethod
+    def kv_unpack(gbuf: torch.Tensor, views, Pp: int, Mx: int, kfull: torch.Tensor, vtfull: torch.Tensor) -> None:
+        """the all-gathered packs [P, 2 Mx C] -> K [S Pp, C] and V^T [C, >= S Pp] of ALL views in view order"""
+        C = kfull.shape[1]
+        for r, (v0, v1) in enumerate(views):
+            Mr = (v1 - v0) * Pp
+            if Mr:
+                kfull[v0 * Pp: v1 * Pp].copy_(gbuf[r, : Mr * C].view(Mr, C))
+                vtfull[:, v0 * Pp: v1 * Pp].copy_(gbuf[r, Mx * C:].view(C, Mx)[:, :Mr])
+
+    @staticmethod
+    def gather_rows(gbuf: torch.Tensor, views, rows_per_view: int, cols: int, max_views: int) -> torch.Tensor:
+        """per-rank padded blocks [P, max_views * rows_per_view * cols] -> the rows of all views in view order"""
+        return torch.cat([gbuf[r].view(max_views * rows_per_view, cols)[: (b - a) * rows_per_view] for r, (a, b) in enumerate(views)], 0)
+
+    @staticmethod
+    def shard_views(S: int, world: int) -> List[tuple]:
+        """[(first view, one past last view)] per rank: contiguous runs, the first S % world ranks hold one view more"""
+        base, extra = divmod(S, world)
+        out, v = [], 0
+        for r in range(world):
+            n = base + (1 if r < extra else 0)
+            out.append((v, v + n))
+            v += n
+        return out
+
+    @torch.no_grad()
+    def forward_sharded(self, S: int, H: int, W: int, tokens: torch.Tensor, img_cl: torch.Tensor, group, timings: Optional[dict] = None) -> dict:
+        """The reconstruction of ONE scene over the `group.world` ranks of a scene-parallel run (BASELINE configs #3 / #4):
+        views are split over ranks (13 -> 7 / 6, 4 / 3 / 3 / 3, ...).  DINO blocks, frame blocks and the DPT heads are per-view
+        (aggregator.py:318-345, dpt_head.py: per-frame 2-D convolutions) and run on the local views only; every global block all-gathers
+        the ranks' K | V^T (aggregator.py:347-373; _attn); the camera head (13 tokens, weight-streaming) runs replicated on the all-gathered
+        camera-token rows; the per-pixel maps are all-gathered once and the voxel / adapter tail (3 ms) runs replicated.  Every row is
+        computed by the same kernels in the same k-order as in `forward_tokens_filled`: the result is bit-identical to the unsharded forward
+        (tests/test_recon_gpu.py::test_view_sharded_forward_is_bit_identical).
+        tokens: [S * Pp, C] bf16 in the layout of `token_workspace` (all views; the stitching convolution is 2e10 FLOP and runs on every
+        rank); img_cl: [S,H,W,8] all views.  Every rank returns the full scene."""
+        import threading
+        cfg, dev = self.cfg, self.dev
+        P_, rk = group.world, group.rank
+        views = self.shard_views(S, P_)
+        v0, v1 = views[rk]
+        Sl, maxS = v1 - v0, max(b - a for a, b in views)
+        tid = threading.get_ident()
+        gl = self._geometry(max(Sl, 1), H, W, tag=("shard", tid))       # (a rank without views still takes part in every collective)
+        C, Pp, nsp, hw, hp, wp = cfg.C, gl["Pp"], gl["nsp"], gl["hw"], gl["hp"], gl["wp"]
+        skey = ("shardbuf", S, H, W, P_, rk, tid)
+        sh = self._geo.get(skey)
+        if sh is None:
+            z = lambda *s_, dt=bf16: torch.zeros(*s_, device=dev, dtype=dt)
+            Mx = maxS * Pp
+            cam0 = torch.cat([self.camera_token[0, 0], self.register_token[0, 0]], 0)
+            cam1 = torch.cat([self.camera_token[0, 1], self.register_token[0, 1]], 0)
+            sp_full = torch.stack([cam0] + [cam1] * (S - 1), 0).to(bf16).float().to(dev)       # view 0 carries the first-frame camera token
+            npx = maxS * H * W
+            sh = self._geo[skey] = dict(pack=z(2 * Mx * C), gbuf=z(P_, 2 * Mx * C), kfull=z(S * Pp, C), vtfull=z(C, S * Pp + 64),
+                                        special_agg=sp_full[v0:v1], cpack=z(maxS, 2 * C, dt=f32), cgbuf=z(P_, maxS * 2 * C, dt=f32),
+                                        opack=z(npx * OUT_COLS, dt=f32), ogbuf=z(P_, npx * OUT_COLS, dt=f32))
+        sh.update(group=group, views=views, S=S, maxS=maxS)
+        ev = (lambda: _ev()) if timings is not None else (lambda: None)
+        e0 = ev()
+        if Sl:
+            gl["form_frames"] = S        # the halo / implicit-GEMM choice of the DPT convolutions follows the SCENE's frame count
+            gl["x"].view(Sl, Pp, C)[:, nsp:nsp + hw] = tokens.view(S, Pp, C)[v0:v1, nsp:nsp + hw]
+            self.backbone(gl, Sl, shard=sh)
+            sh["cpack"][:Sl] = gl["taps"][-1].view(Sl, Pp, 2 * C)[:, 0]
+        else:
+            for _ in range(cfg.depth):   # stay in lockstep with the ranks that own views
+                group.all_gather(sh["gbuf"], sh["pack"]).wait()
+        group.all_gather(sh["cgbuf"], sh["cpack"]).wait()
+        ptok = self.gather_rows(sh["cgbuf"], views, 1, 2 * C, maxS)     # [S, 2C] in view order
+        e1 = ev()
+        poses = self.camera(gl, S, pose_tokens=ptok)
+        e2 = ev()
+        op = sh["opack"]
+        HW = H * W
+        if Sl:
+            depth, dconf, pts, raw_gs, _, _ = self.heads(gl, Sl, H, W, img_cl[v0:v1], poses[-1][v0:v1])
+            o2 = op.view(maxS * HW, OUT_COLS)
+            o2[: Sl * HW, 0], o2[: Sl * HW, 1] = depth.reshape(-1), dconf.reshape(-1)
+            o2[: Sl * HW, 2:5] = pts.reshape(-1, 3)
+            o2[: Sl * HW, 5:] = raw_gs
+        e3 = ev()
+        group.all_gather(sh["ogbuf"], op).wait()
+        allv = self.gather_rows(sh["ogbuf"], views, HW, OUT_COLS, maxS)     # [S H W, 93] in view order
+        depth, dconf = allv[:, 0].reshape(S, H, W).contiguous(), allv[:, 1].reshape(S, H, W).contiguous()
+        pts, raw_gs = allv[:, 2:5].reshape(S, H, W, 3).contiguous(), allv[:, 5:].contiguous()
+        ext, K = pose_encoding_to_extri_intri(poses[-1], (H, W))
+        out = self._tail(S, H, W, poses, depth, dconf, pts, raw_gs, ext, K)
+        e4 = ev()
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings.update(views=[Sl, S], backbone_ms=e0.elapsed_time(e1), camera_ms=e1.elapsed_time(e2), heads_ms=e2.elapsed_time(e3),
+                           gather_and_tail_ms=e3.elapsed_time(e4))
+        return out
+
+    def token_buffer(self, S: int, H: int, W: int, tag) -> torch.Tensor:
+        """a private [S * Pp, C] bf16 token buffer in the workspace layout (view-sharded forward: one per rank / virtual rank)"""
+        g = self._geometry(S, H, W)
+        key = ("tokbuf", S, H, W, tag)
+        t = self._geo.get(key)
+        if t is None:
+            t = self._geo[key] = torch.zeros(S * g["Pp"], self.cfg.C, device=self.dev, dtype=bf16)
+        return t
+
     def token_workspace(self, S: int, H: int, W: int):
         """(x [S*Pp, C] bf16, geometry dict): the stitching conv writes patch tokens into x via out_rows=(hw, Pp-hw, nsp)."""
         g = self._geometry(S, H, W)
@@ -469,6 +606,15 @@ class ReconEngine:
         img_cl = torch.zeros(S, H, W, 8, device=self.dev, dtype=f32)
         img_cl[..., :3] = img
         return self.forward_tokens_filled(S, H, W, img_cl)
+
+
+OUT_COLS = 93    # per-pixel outputs a rank contributes to the final all-gather: depth, depth_conf, xyz, 88 raw head columns
+
+
+def _ev():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
 
 
 def quat_to_mat(q: torch.Tensor) -> torch.Tensor:

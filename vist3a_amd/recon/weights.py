@@ -13,9 +13,13 @@ from .engine import ReconCfg
 SD = Dict[str, torch.Tensor]
 
 
-def random_recon_state_dict(cfg: ReconCfg, seed: int = 0, device="cpu", n_pos: int = 1370, n_reg: int = 4) -> SD:
+def random_recon_state_dict(cfg: ReconCfg, seed: int = 0, device="cpu", n_pos: int = 1370, n_reg: int = 4, scene_like: bool = False) -> SD:
     """Linear/Conv ~ N(0, 1/fan_in) (keeps activations O(1) through 70 blocks), norm gamma ~ 1, LayerScale as the
-    reference initialises it (DINO 1.0, aggregator / camera head 0.01), tokens ~ N(0, 0.02)."""
+    reference initialises it (DINO 1.0, aggregator / camera head 0.01), tokens ~ N(0, 0.02).
+    scene_like: the camera head's last layer gets the bias of a plausible camera (identity rotation, 57 degree field of view) instead of a
+    near-zero pose encoding.  With fov ~ 0 the intrinsics are fx = (W / 2) / (tan(fov / 2) + 1e-3) ~ 2e5 px: every ray is parallel, the
+    13 x 448^2 points of a scene fall inside a 2 mm column and collapse into ~35 k voxels of ~76 points - a degenerate input for the
+    voxel fusion / adapter / rasteriser tail.  A trained checkpoint spreads them over 1-2 M voxels; so does this bias (bench.py)."""
     g = torch.Generator(device=device).manual_seed(seed)
     rn = lambda *s, std=1.0: torch.randn(*s, generator=g, device=device) * std
     sd: SD = {}
@@ -67,6 +71,9 @@ def random_recon_state_dict(cfg: ReconCfg, seed: int = 0, device="cpu", n_pos: i
     lin(c + "pose_branch.fc1", C2 // 2, C2)
     lin(c + "pose_branch.fc2", 9, C2 // 2)
     sd[c + "pose_branch.fc2.weight"] *= 0.1
+    if scene_like:   # pose encoding = (T, quaternion xyzw, fov_h, fov_w): vggt/utils/pose_enc.py:65-130
+        # (the head refines the encoding in four additive iterations, camera_head.py:118-160: a quarter of the target per iteration)
+        sd[c + "pose_branch.fc2.bias"] = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.25, 0.25, 0.25], device=device)
 
     def conv(name, o, i, k, bias=True, tr=False):
         shape = (i, o, k, k) if tr else (o, i, k, k)

@@ -59,7 +59,7 @@ class Text23DGS:
         vcfg = vae_cfg or WanVAEConfig()
         vae = WanVAEDecoder(vcfg, random_vae_decoder_state_dict(vcfg, seed + 1, device), device=device)
         rcfg = recon_cfg or ReconCfg()
-        rsd = round_aggregator_to_bf16(random_recon_state_dict(rcfg, seed=seed + 2, device=device))
+        rsd = round_aggregator_to_bf16(random_recon_state_dict(rcfg, seed=seed + 2, device=device, scene_like=True))
         dec = StitchVAE3D(vae, AnySplatWeights(rsd, rcfg), device, stitch_location, parse_conv_spec(stitch_spec), resolution)
         g = torch.Generator().manual_seed(seed + 3)
         with torch.no_grad():

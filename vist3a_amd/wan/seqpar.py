@@ -123,6 +123,7 @@ class DenoisePlan:
     """How one scene's denoise is spread over ranks: `cfg` = 2-rank cond/uncond split, `sp` = token shards of the DiT."""
     sp: Optional[object] = None
     cfg: Optional[object] = None
+    world: Optional[object] = None     # all ranks of the scene: the view-sharded reconstruction (recon/engine.py forward_sharded)
 
     @staticmethod
     def layout(world: int) -> Tuple[int, int]:
@@ -151,7 +152,8 @@ class DenoisePlan:
                 pg = dist.new_group(ranks)
                 if rank in ranks:
                     cfg = DistGroup(ranks, rank, pg)
-        return cls(sp=sp, cfg=cfg)
+        wg = DistGroup(list(range(world)), rank, None) if world > 1 else None     # (pg None = the default process group)
+        return cls(sp=sp, cfg=cfg, world=wg)
 
     @classmethod
     def from_threads(cls, world: int) -> List["DenoisePlan"]:
@@ -160,8 +162,9 @@ class DenoisePlan:
         sp_worlds = [ThreadWorld(sp_deg) for _ in range(cfg_deg)] if sp_deg > 1 else None
         cfg_worlds = [ThreadWorld(2) for _ in range(sp_deg)] if cfg_deg == 2 else None
         plans = []
+        ww = ThreadWorld(world) if world > 1 else None
         for r in range(world):
             c, s = divmod(r, sp_deg)
             plans.append(cls(sp=sp_worlds[c].group(s) if sp_worlds else None,
-                             cfg=cfg_worlds[s].group(c) if cfg_worlds else None))
+                             cfg=cfg_worlds[s].group(c) if cfg_worlds else None, world=ww.group(r) if ww else None))
         return plans
