@@ -279,8 +279,11 @@ def test_config4_14b_width_eight_blocks_match_oracle(hip_lib, parity):
     parity("dit_config4_14B_width_8_blocks", bf16_vs_contract_by_depth={str(k): v for k, v in c16.items()},
            fp8_attention_vs_e4m3_oracle_by_depth={str(k): v for k, v in c8.items()})
     print("config #4, 14B width, by depth: bf16", {k: f"{v:.2e}" for k, v in c16.items()}, "fp8 attention", {k: f"{v:.2e}" for k, v in c8.items()})
-    assert c16[1] < TOL_ONE_BLOCK and c8[1] < 2 * TOL_ONE_BLOCK, (c16, c8)
-    assert c16[8] < 1.2e-2 and c8[8] < 2.4e-2, (c16, c8)     # measured 5.6e-3 / 1.1e-2 after eight blocks
+    # measured on MI355X: bf16 3.5e-3 / 4.9e-3 / 6.6e-3 / 8.4e-3 after 1 / 2 / 4 / 8 blocks, fp8 attention 3.6e-3 / 5.2e-3 / 7.1e-3 / 9.1e-3
+    # (one block at this width is 2.3x the 1.3B-width figure: 3.3x longer bf16 reductions; the curve grows like sqrt(depth), no faster)
+    assert c16[1] < 7e-3 and c8[1] < 7.2e-3, (c16, c8)
+    assert c16[8] < 1.7e-2 and c8[8] < 1.8e-2, (c16, c8)
+    assert c16[8] < 3.2 * c16[1] and c8[8] < 3.2 * c8[1], (c16, c8)      # sqrt(8) = 2.8: an error that compounds faster than rounding noise fails
 
 
 def test_config4_full_depth_14b_forward_is_deterministic_and_finite(hip_lib, parity):

@@ -63,6 +63,40 @@ def test_voxel_large_random_vs_oracle(hip_lib):
     assert torch.allclose(v["voxel_pts"].cpu(), vp, atol=1e-6) and torch.allclose(v["voxel_feat"].cpu(), vf, atol=1e-5)
 
 
+@pytest.mark.parametrize("cloud", ["crowded", "one_voxel", "chunk_edges", "spread"])
+def test_voxel_fusion_any_distribution_vs_oracle(hip_lib, cloud):
+    """The fusion pass is a segmented reduction over fixed 64-point chunks of the sorted points (csrc/voxel.hip): voxels inside a chunk,
+    voxels spanning two chunks, voxels of thousands of points spanning dozens, a cloud that is ONE voxel, voxels that begin / end exactly
+    on chunk edges - integer outputs bit-exact, fused values to fp32 round-off of the oracle's scatter softmax; run-to-run bit identity."""
+    from vist3a_amd import ops
+    gen = torch.Generator().manual_seed({"crowded": 1, "one_voxel": 2, "chunk_edges": 3, "spread": 4}[cloud])
+    C = 83
+    if cloud == "crowded":      # 40 000 points in ~300 voxels, one of them with ~8000 points
+        pts = torch.randn(40000, 3, generator=gen) * 0.004
+        pts[:8000] = torch.tensor([0.0101, 0.0101, 0.0101]) + torch.rand(8000, 3, generator=gen) * 0.0005
+    elif cloud == "one_voxel":
+        pts = torch.rand(5000, 3, generator=gen) * 0.0005 + 0.1
+    elif cloud == "chunk_edges":   # voxels of exactly 64, 128, 1, 63, 65 points, ... : boundaries on and next to chunk edges
+        sizes = [64, 128, 1, 63, 65, 64, 1, 1, 62, 192, 3, 61]
+        pts = torch.cat([torch.full((n, 3), 0.01 * (i + 1)) + torch.rand(n, 3, generator=gen) * 0.0004 for i, n in enumerate(sizes)])
+    else:
+        pts = torch.randn(30000, 3, generator=gen) * 0.05
+    M = pts.shape[0]
+    pts = pts[torch.randperm(M, generator=gen)]          # original order is not sorted order
+    feat, conf = torch.randn(M, C, generator=gen), torch.randn(M, generator=gen) * 3
+    vp, vf, keys, inv, cnt = R.voxelize_with_fusion(feat.t().reshape(1, C, M, 1), pts.t().reshape(1, 3, M, 1), 0.002, conf.reshape(1, M, 1))
+    f2 = torch.cat([feat, conf[:, None], torch.zeros(M, 4)], 1).contiguous().cuda()
+    v = ops.voxelize_fuse(pts.contiguous().cuda(), f2, C, C, 0.002)
+    assert torch.equal(v["keys"].cpu(), keys) and torch.equal(v["inverse"].cpu().long(), inv) and torch.equal(v["counts"].cpu().long(), cnt)
+    if cloud == "chunk_edges":
+        assert sorted(cnt.tolist()) == sorted(sizes)
+    if cloud == "one_voxel":
+        assert keys.shape[0] == 1
+    assert torch.allclose(v["voxel_pts"].cpu(), vp, atol=2e-6, rtol=1e-5) and torch.allclose(v["voxel_feat"].cpu(), vf, atol=2e-5, rtol=1e-4)
+    v2 = ops.voxelize_fuse(pts.contiguous().cuda(), f2, C, C, 0.002)
+    assert torch.equal(v2["voxel_feat"], v["voxel_feat"]) and torch.equal(v2["voxel_pts"], v["voxel_pts"])
+
+
 def test_engine_matches_reference_golden(tiny):
     ocfg, sd, eng = tiny
     g = load_file(str(G / "recon_tiny.safetensors"))

@@ -726,7 +726,13 @@ int pick_tile(int M, int N, bool conv = false, int mult = 1, int act = 0) {
 }
 
 int launch(const GemmP& p, int ti, int conv, void* stream, int nz = 1) {   // conv: 0 GEMM, 1 convolution, 2 split-bf16 convolution
-  if (ti < 0 || ti >= kNumTiles) ti = pick_tile(p.M, p.N, conv != 0, nz, p.act);
+  if (ti < 0 || ti >= kNumTiles) {
+    ti = pick_tile(p.M, p.N, conv != 0, nz, p.act);
+    // split-bf16 convolutions walk a 3x longer K: a layer that cannot give every CU a big tile (the 16^2 / 32^2 levels of the DPT pyramid:
+    // < 128 tiles of 256 x 256) is latency-bound per tile and wants MANY small co-resident tiles (tools/conv_split_sweep.py, 13 views:
+    // 1024 -> 1024 stride 2 at 32^2 0.56 -> 0.40 ms, 1024 -> 256 at 32^2 0.55 -> 0.39, 256 -> 256 at 32^2 0.148 -> 0.100)
+    if (conv == 2 && (long)((p.M + 255) / 256) * ((p.N + 255) / 256) < 128) ti = (p.M <= 4096 && p.N <= 256) ? 11 : 9;
+  }
   const TileEntry& e = kTiles[ti];
   const gemm_fn fn = conv == 2 ? e.split_fn : conv ? e.conv_fn : e.fn;
   if (!fn) return V3A_ERR_ARG;  // this tile shape has no conv instantiation

@@ -6,7 +6,7 @@
 // ((kx+2^20)<<42 | (ky+2^20)<<21 | (kz+2^20)) sorted with a stable LSD radix sort (rocPRIM device primitive, the one
 // library call in this file), run-length boundaries by an exclusive scan.  Because the sort is stable, every voxel's
 // points appear in ascending original index: the float sums have ONE defined order (the reference's CUDA atomics
-// have none).  The fusion pass gives a 16-lane group to a voxel (see fuse_kernel).
+// have none).  The fusion pass is a segmented reduction over fixed chunks of the sorted points (see fuse_chunk_kernel).
 #include "common.h"
 #include "../../include/vist3a_hip.h"
 #include <cstring>
@@ -59,77 +59,136 @@ __global__ __launch_bounds__(256) void segments_kernel(const SegP p) {
   if (i == p.M - 1) { *p.U = (int)(u + 1); p.start[u + 1] = (unsigned)p.M; }
 }
 
+constexpr int CH = 64;      // sorted points per fusion chunk
+
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {   // exact and order-independent: the result is deterministic
+  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  else atomicMin((unsigned int*)addr, __float_as_uint(v));
+}
+
+// per sorted point: its confidence (gathered once, then read coalesced) and the running maximum of its voxel
+struct CMaxP { const float* feat; int ldf, conf_col; const unsigned int* idx; const unsigned int* vid; long M; float* csorted; float* vmax; };
+__global__ __launch_bounds__(256) void conf_max_kernel(const CMaxP p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.M) return;
+  const float c = p.feat[(size_t)p.idx[i] * p.ldf + p.conf_col];
+  p.csorted[i] = c;
+  atomic_max_f32(p.vmax + (p.vid[i] - 1), c);
+}
+
 struct FuseP {
-  const float* pts; const float* feat; int ldf, nfeat, conf_col;
-  const unsigned int* idx; const unsigned int* start; const int* U;
-  float* vpts; float* vfeat; int ldo; int* counts;
+  const float* pts; const float* feat; int ldf, nfeat;
+  const unsigned int* idx; const unsigned int* vid; const float* csorted; const float* vmax; long M;
+  float* vpts; float* vfeat; int ldo; float* spill;
 };
-// One 16-LANE GROUP per voxel (four voxels per wave, grid-stride): real scenes put 1-3 points in a voxel, so a whole wave per
-// voxel idles 3/4 of its lanes and serialises four dependent round trips (start -> idx -> confidence -> row) per voxel.
-// Per voxel: (1) the group gathers the confidences of its points 16 at a time and reduces the maximum with 4 shuffles;
-// (2) ONE pass over the points in sorted (= ascending original index) order: e_j = exp(c_j - max) is computed 16 points at a
-// time (lane i holds point i), then for each point its row index and e_j are broadcast inside the group and the row is read as
-// NK independent 64-byte pieces (lane sl takes channels sl + 16 k): NK loads in flight per point, accumulated with one FMA each.
-// The normaliser is applied once at the end: sum_j f_j e_j / (sum_j e_j + 1e-6)  ==  sum_j f_j softmax_j  up to one rounding.
-// Every sum runs in a fixed order (points ascending, then a fixed shuffle tree for the denominator): results do not depend on
-// scheduling.  Replaces the three-serial-passes-per-wave kernel that ran at 1 % of HBM bandwidth (11.4 ms per scene).
+// Confidence-softmax fusion as a SEGMENTED REDUCTION OVER FIXED CHUNKS of the sorted point list: a 16-lane group owns CH = 64 consecutive
+// sorted points whatever voxels they belong to, so the work per group does not depend on the cloud - a trained checkpoint puts 1-3 points
+// in a voxel, seeded random weights can put thousands in one (the round-4 kernel, one group per VOXEL, ran such a cloud at 7 % of the HBM
+// rate: the largest voxel was a serial chain on 16 lanes).  Per chunk: e_j = exp(c_j - max of the voxel) for 16 points at a time, the rows
+// of four points requested together (NK 64-byte pieces each: lane sl takes channels sl + 16 k), FMAs in ascending point order.  When the
+// voxel id changes the finished voxel is flushed: normalised and written if it lies inside the chunk (bit-identical to a serial sum over
+// its points), else left as a PARTIAL (lead = the chunk begins inside the voxel, tail = it ends inside it) that fuse_combine_kernel sums
+// in chunk order.  Every sum has one defined order: results do not depend on scheduling.
 template <int NK>
-__global__ __launch_bounds__(256) void fuse_kernel(const FuseP p) {
+__global__ __launch_bounds__(256) void fuse_chunk_kernel(const FuseP p) {
   const int lane = threadIdx.x & 63, sl = lane & 15, gbase = lane & 48;
-  const int U = *p.U;
-  const int ngroups = gridDim.x * 16;
+  const long c = ((long)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const long j_begin = c * CH;
+  if (j_begin >= p.M) return;
+  const long j_end = min(j_begin + CH, p.M);
+  constexpr int PS = (NK + 2) * 16;      // floats per partial: NK feature slots, one xyz slot, one denominator slot (x 16 lanes)
+  float* lead = p.spill + (size_t)c * 2 * PS;
+  float* tail = lead + PS;
   const size_t ldf = (size_t)p.ldf;
-  for (int u = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4); u < U; u += ngroups) {
+  unsigned cur = p.vid[j_begin];
+  bool inside = j_begin == 0 || p.vid[j_begin - 1] != cur;    // the current voxel began in this chunk
+  float acc[NK], ap = 0.f, den = 0.f;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) acc[k] = 0.f;
+  auto flush = [&](bool ends_here) {     // voxel `cur` is done for this chunk
+    if (inside && ends_here) {
+      const float inv = 1.0f / (den + 1e-6f);
+      const size_t u = cur - 1;
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+        if (sl + 16 * k < p.nfeat) p.vfeat[u * p.ldo + sl + 16 * k] = acc[k] * inv;
+      if (sl < 3) p.vpts[u * 3 + sl] = ap * inv;
+    } else {
+      float* dst = inside ? tail : lead;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) dst[k * 16 + sl] = acc[k];
+      dst[NK * 16 + sl] = ap;
+      dst[(NK + 1) * 16 + sl] = den;
+    }
+  };
+  for (long j0 = j_begin; j0 < j_end; j0 += 16) {
+    const long j = j0 + sl;
+    unsigned myr = 0, myv = 0;
+    float mye = 0.f;
+    if (j < j_end) {
+      myr = p.idx[j];
+      myv = p.vid[j];
+      mye = expf(p.csorted[j] - p.vmax[myv - 1]);
+    }
+    const int cnt = (int)min(16L, j_end - j0);
+    for (int i = 0; i < cnt; i += 4) {
+      float v[4][NK], pv[4], w[4];
+      unsigned vv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int src = gbase + min(i + q, 15);
+        const size_t r = (size_t)__shfl(myr, src, 64);
+        w[q] = __shfl(mye, src, 64);
+        vv[q] = __shfl(myv, src, 64);
+        const float* row = p.feat + r * ldf;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) v[q][k] = (i + q < cnt && sl + 16 * k < p.nfeat) ? row[sl + 16 * k] : 0.f;
+        pv[q] = (i + q < cnt && sl < 3) ? p.pts[r * 3 + sl] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i + q < cnt) {
+          if (vv[q] != cur) {
+            flush(true);
+            cur = vv[q]; inside = true; ap = 0.f; den = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) acc[k] = 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < NK; ++k) acc[k] = fmaf(v[q][k], w[q], acc[k]);
+          ap = fmaf(pv[q], w[q], ap);
+          den += w[q];
+        }
+      }
+    }
+  }
+  flush(j_end == p.M || p.vid[j_end] != cur);
+}
+
+// voxels that span several chunks: tail partial of the chunk they begin in + lead partials of the following ones, in chunk order;
+// and the point count of every voxel
+struct CombP { const unsigned int* start; const int* U; const float* spill; float* vpts; float* vfeat; int ldo, nfeat; int* counts; };
+template <int NK>
+__global__ __launch_bounds__(256) void fuse_combine_kernel(const CombP p) {
+  const int sl = threadIdx.x & 15;
+  const int U = *p.U;
+  constexpr int PS = (NK + 2) * 16;
+  for (long u = ((long)blockIdx.x * 256 + threadIdx.x) >> 4; u < U; u += (long)gridDim.x * 16) {
     const unsigned s = p.start[u], e = p.start[u + 1];
     if (sl == 0) p.counts[u] = (int)(e - s);
-    float mx = -INFINITY;
-    for (unsigned j0 = s; j0 < e; j0 += 16) {
-      const unsigned j = j0 + sl;
-      if (j < e) mx = fmaxf(mx, p.feat[(size_t)p.idx[j] * ldf + p.conf_col]);
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
-    float acc[NK], ap = 0.f, dpart = 0.f;
+    const unsigned c0 = s / CH, c1 = (e - 1) / CH;
+    if (c0 == c1) continue;      // written by fuse_chunk_kernel
+    float acc[NK], ap = 0.f, den = 0.f;
 #pragma unroll
     for (int k = 0; k < NK; ++k) acc[k] = 0.f;
-    for (unsigned j0 = s; j0 < e; j0 += 16) {
-      const unsigned j = j0 + sl;
-      unsigned myr = 0;
-      float mye = 0.f;
-      if (j < e) {
-        myr = p.idx[j];
-        mye = expf(p.feat[(size_t)myr * ldf + p.conf_col] - mx);
-      }
-      dpart += mye;
-      const int cnt = (int)min(16u, e - j0);
-      // four points per trip: their rows are requested together (4 x NK loads in flight instead of NK - a crowded voxel, e.g. the
-      // collapsed cloud of seeded random weights with ~76 points per voxel, is a serial chain of row fetches otherwise: 4.3 ms per scene),
-      // the FMAs then run in the same ascending point order as before
-      for (int i = 0; i < cnt; i += 4) {
-        float v[4][NK], pv[4], w[4];
+    for (unsigned c = c0; c <= c1; ++c) {
+      const float* src = p.spill + (size_t)c * 2 * PS + (c == c0 ? PS : 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int src = gbase + min(i + q, 15);
-          const size_t r = (size_t)__shfl(myr, src, 64);
-          w[q] = __shfl(mye, src, 64);
-          const float* row = p.feat + r * ldf;
-#pragma unroll
-          for (int k = 0; k < NK; ++k) v[q][k] = (i + q < cnt && sl + 16 * k < p.nfeat) ? row[sl + 16 * k] : 0.f;
-          pv[q] = (i + q < cnt && sl < 3) ? p.pts[r * 3 + sl] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (i + q < cnt) {
-#pragma unroll
-            for (int k = 0; k < NK; ++k) acc[k] = fmaf(v[q][k], w[q], acc[k]);
-            ap = fmaf(pv[q], w[q], ap);
-          }
-        }
-      }
+      for (int k = 0; k < NK; ++k) acc[k] += src[k * 16 + sl];
+      ap += src[NK * 16 + sl];
+      den += src[(NK + 1) * 16 + sl];
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) dpart += __shfl_xor(dpart, o, 16);
-    const float inv = 1.0f / (dpart + 1e-6f);
+    const float inv = 1.0f / (den + 1e-6f);
 #pragma unroll
     for (int k = 0; k < NK; ++k)
       if (sl + 16 * k < p.nfeat) p.vfeat[(size_t)u * p.ldo + sl + 16 * k] = acc[k] * inv;
@@ -140,7 +199,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(const FuseP p) {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t key_in, key_out, idx_in, idx_out, head, vid, start, tmp, tmp_bytes, total;
+  size_t key_in, key_out, idx_in, idx_out, head, vid, start, spill, tmp, tmp_bytes, total;
 };
 Layout layout(long M) {
   Layout l{};
@@ -149,6 +208,7 @@ Layout layout(long M) {
   l.key_in = take(M * 8); l.key_out = take(M * 8);
   l.idx_in = take(M * 4); l.idx_out = take(M * 4);
   l.head = take(M * 4); l.vid = take(M * 4); l.start = take((M + 1) * 4);
+  l.spill = take(((size_t)(M + CH - 1) / CH) * 2 * (8 + 2) * 16 * 4);   // (lead, tail) partials of every fusion chunk, NK <= 8
   size_t t1 = 0, t2 = 0;
   (void)rocprim::radix_sort_pairs(nullptr, t1, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned int*)nullptr,
                             (unsigned int*)nullptr, (size_t)M, 0, 63);
@@ -250,10 +310,25 @@ extern "C" int v3a_voxelize_fuse(const float* pts, const float* feat, int ldf, i
     return V3A_ERR_LAUNCH;
   hipLaunchKernelGGL(segments_kernel, dim3(nb), dim3(256), 0, stream,
                      SegP{key_out, idx_out, head, vid, M, keys_out, inverse_out, start, num_voxels});
-  const FuseP fp{pts, feat, ldf, nfeat, conf_col, idx_out, start, num_voxels, voxel_pts, voxel_feat, ldo, counts_out};
-  if (nfeat <= 32) hipLaunchKernelGGL(fuse_kernel<2>, dim3(2048), dim3(256), 0, stream, fp);
-  else if (nfeat <= 96) hipLaunchKernelGGL(fuse_kernel<6>, dim3(2048), dim3(256), 0, stream, fp);
-  else hipLaunchKernelGGL(fuse_kernel<8>, dim3(2048), dim3(256), 0, stream, fp);
+  // after the sort key_in (8 M bytes) is free: the sorted confidences and the per-voxel maxima live there
+  float* csorted = (float*)key_in;
+  float* vmax = csorted + M;
+  if (hipMemsetD32Async((hipDeviceptr_t)vmax, 0xff800000u, (size_t)M, stream) != hipSuccess) return V3A_ERR_LAUNCH;   // -inf
+  hipLaunchKernelGGL(conf_max_kernel, dim3(nb), dim3(256), 0, stream, CMaxP{feat, ldf, conf_col, idx_out, vid, M, csorted, vmax});
+  float* spill = (float*)(ws + l.spill);
+  const FuseP fp{pts, feat, ldf, nfeat, idx_out, vid, csorted, vmax, M, voxel_pts, voxel_feat, ldo, spill};
+  const CombP cp{start, num_voxels, spill, voxel_pts, voxel_feat, ldo, nfeat, counts_out};
+  const unsigned nchunk_blocks = (unsigned)(((M + CH - 1) / CH + 15) / 16);
+  if (nfeat <= 32) {
+    hipLaunchKernelGGL(fuse_chunk_kernel<2>, dim3(nchunk_blocks), dim3(256), 0, stream, fp);
+    hipLaunchKernelGGL(fuse_combine_kernel<2>, dim3(2048), dim3(256), 0, stream, cp);
+  } else if (nfeat <= 96) {
+    hipLaunchKernelGGL(fuse_chunk_kernel<6>, dim3(nchunk_blocks), dim3(256), 0, stream, fp);
+    hipLaunchKernelGGL(fuse_combine_kernel<6>, dim3(2048), dim3(256), 0, stream, cp);
+  } else {
+    hipLaunchKernelGGL(fuse_chunk_kernel<8>, dim3(nchunk_blocks), dim3(256), 0, stream, fp);
+    hipLaunchKernelGGL(fuse_combine_kernel<8>, dim3(2048), dim3(256), 0, stream, cp);
+  }
   return hipGetLastError() == hipSuccess ? V3A_OK : V3A_ERR_LAUNCH;
 }
 
