@@ -145,7 +145,10 @@ typedef struct {
    * Layout: w_halo[Cout/96][kT][Cin/48][9 = dh*3+dw][96 rows n][48 k] bf16, where the six 16-byte chunks of a row are stored
    * rotated: logical chunk c of row n sits at position (c + 3*((n >> 3) & 1)) % 6 (the kernel's LDS bank layout; the slab is
    * copied to LDS verbatim).  NULL = implicit-GEMM path only.  v3a_conv_bf16 takes the halo kernel when w_halo is set, the layer
-   * has this form, tile < 0 and v3a_conv_halo_tiles(args) >= 512; tile == -2 forces it, tile == -3 forbids it. */
+   * has this form, tile < 0 and v3a_conv_halo_tiles(args) >= 512; tile == -2 forces it, tile == -3 forbids it.
+   * H-STRIPS (a spatially sharded image: wan/vae.py decode_cl_sharded): the stored input may carry ONE explicit halo row above and below
+   * every frame and be convolved VALID in H - pH = 0 with H = oH + 2, or with ups2 pH = -1 with 2 (H - 2) = oH (output row j reads rows
+   * j + 1 + dh of the 2x upsampled haloed strip).  Both kernels take it (negative pH is plain arithmetic in the implicit GEMM). */
   const void* w_halo; int halo_kT;
 } v3a_conv_args;
 int v3a_conv_bf16(const v3a_conv_args* args, void* stream);

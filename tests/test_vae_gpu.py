@@ -100,3 +100,26 @@ def test_encode_surface_and_roundtrip_shapes(hip_lib):
     assert torch.allclose(z1.cpu(), OV.posterior_sample(dist.parameters.cpu(), noise), atol=1e-6)
     video = vae.decode(dist.mode())[0]
     assert video.shape == (1, 3, 5, 32, 32)
+
+
+@pytest.mark.parametrize("shape,worlds", [((1, 16, 2, 32, 32), (2, 4)), ((1, 16, 4, 64, 64), (8,))])
+def test_strip_sharded_decode_is_bit_identical(hip_lib, shape, worlds):
+    """SURVEY 8(e) "VAE under SP": `WanVAEDecoder.decode_cl_sharded` - the decoder's up blocks on H-strips over the ranks of a scene-parallel
+    run, boundary rows exchanged before every 3x3 convolution, the halo-tile and implicit-GEMM kernels convolving haloed strips VALID in H
+    (plain and with the fused 2x upsample) - returns, on every rank, exactly the clip of the unsharded `decode_cl`.  Production width
+    (base_dim 96); 5 x 256^2 over 2 / 4 virtual ranks and the production 13 x 512^2 clip over 8 (threads on this GPU, seqpar.ThreadWorld)."""
+    from oracle import wan_vae as OV
+    from vist3a_amd.wan.seqpar import ThreadWorld
+    from vist3a_amd.wan.vae import WanVAEConfig, WanVAEDecoder
+    dec = WanVAEDecoder(WanVAEConfig(), OV.make_weights(OV.WanVAEConfig(), seed=31))
+    z = torch.randn(*shape, generator=torch.Generator().manual_seed(34)).cuda()
+    ref = dec.decode_cl(z).clone()
+    assert ref.abs().max() > 0.1
+    for P in worlds:
+        w = ThreadWorld(P)
+        outs = w.run(lambda r: dec.decode_cl_sharded(z, w.group(r)).clone())
+        torch.cuda.synchronize()
+        for o in outs:
+            assert o.shape == ref.shape and torch.equal(o, ref), (P, (o.float() - ref.float()).abs().max().item())
+    with pytest.raises(ValueError):
+        dec.decode_cl_sharded(z, ThreadWorld(3).group(0))       # 32 / 64 latent rows do not split into 3 strips

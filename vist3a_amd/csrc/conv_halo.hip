@@ -50,6 +50,8 @@ struct HaloP {
   int cH, cW, Cin;       // stored input extent
   int kT, ups;
   int tilesH, tilesW, nN;
+  int inhalo;            // 1: the stored input carries ONE explicit halo row above and below every frame (cH = its rows incl. the two halo rows): an
+                         //    H-strip of a spatially sharded image, whose neighbours' boundary rows (or zeros at the image border) were put there
 };
 
 // instructions wave w issues in a tap of a step: B slab pieces i < NBI, patch pieces behind them
@@ -99,8 +101,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const HaloP P) {
     const int px = q / 6, s = q - px * 6;
     const int ph = px / HW, pw = px - ph * HW;
     const int hh = h0 - 1 + ph, ww = w0 - 1 + pw;
-    ok = g < NPIECE && px < NPIX && hh >= 0 && hh < P.H && ww >= 0 && ww < P.W;
-    const int hs = P.ups ? hh >> 1 : hh, ws = P.ups ? ww >> 1 : ww;
+    ok = g < NPIECE && px < NPIX && (P.inhalo || (hh >= 0 && hh < P.H)) && ww >= 0 && ww < P.W;
+    // (arithmetic shift: row -1 of the 2x upsampled strip is stored row -1, i.e. halo row 0)
+    const int hs = (P.ups ? hh >> 1 : hh) + P.inhalo, ws = P.ups ? ww >> 1 : ww;
     int c = s - 3 * ((px >> 3) & 1);     // LDS position s of pixel px holds logical chunk c
     c += c < 0 ? 6 : 0;
     off = ok ? ((hs * P.cW + ws) * P.Cin + c * 8) * 2 : 0;
@@ -238,25 +241,42 @@ __global__ __launch_bounds__(512, 2) void conv_halo_kernel(const HaloP P) {
 
 bool g_attr_set = false;
 
+// An H-strip with explicit halo rows (a spatially sharded image, wan/vae.py decode_cl_sharded): the stored input has one more row above and
+// below than the output needs centre rows for, and the convolution is VALID in H.  Spelled through the ordinary geometry fields:
+//   plain:  pH = 0,  H = oH + 2;        fused 2x upsample:  pH = -1,  2 (H - 2) = oH   (taps of output row j read upsampled rows j + 1 + dh)
+inline bool explicit_h_halo(const v3a_conv_args* a) {
+  return a->ups2 ? (a->pH == -1 && 2 * (a->H - 2) == a->oH) : (a->pH == 0 && a->H == a->oH + 2);
+}
+// the layer has this kernel's form (conv_bf16 falls back to the implicit GEMM otherwise)
+inline bool halo_form(const v3a_conv_args* a) {
+  const int kT = a->halo_kT;
+  if (kT != 1 && kT != 3) return false;
+  if (a->sT != 1 || a->sH != 1 || a->sW != 1 || a->pW != 1 || a->pT != kT - 1 || a->replicate) return false;
+  if (a->Cin % CK || a->Cout % BN || a->oH % TH || a->oW % TW) return false;
+  const int eW = a->ups2 ? 2 * a->W : a->W;
+  if (a->oW != eW || a->oT != a->T) return false;
+  if (!explicit_h_halo(a)) {
+    const int eH = a->ups2 ? 2 * a->H : a->H;
+    if (a->pH != 1 || a->oH != eH) return false;
+  }
+  return a->out_row_group <= 0 && !(a->flags & V3A_GEMM_SCALE_PER_BATCH);
+}
+
 }  // namespace
 
 // Eligibility + launch; returns V3A_ERR_SHAPE when the layer is not of this kernel's form (the caller falls back to the implicit GEMM).
 int v3a_conv_halo_launch(const v3a_conv_args* a, void* stream) {
   if (!a->w_halo) return V3A_ERR_SHAPE;
   const int kT = a->halo_kT;
-  if (kT != 1 && kT != 3) return V3A_ERR_SHAPE;
-  if (a->sT != 1 || a->sH != 1 || a->sW != 1 || a->pH != 1 || a->pW != 1 || a->pT != kT - 1 || a->replicate) return V3A_ERR_SHAPE;
-  if (a->Cin % CK || a->Cout % BN || a->oH % TH || a->oW % TW) return V3A_ERR_SHAPE;
-  const int eH = a->ups2 ? 2 * a->H : a->H, eW = a->ups2 ? 2 * a->W : a->W;
-  if (a->oH != eH || a->oW != eW || a->oT != a->T) return V3A_ERR_SHAPE;
-  if (a->out_row_group > 0 || (a->flags & V3A_GEMM_SCALE_PER_BATCH)) return V3A_ERR_SHAPE;
+  if (!halo_form(a)) return V3A_ERR_SHAPE;
+  const int inhalo = explicit_h_halo(a) ? 1 : 0;
   if ((size_t)a->H * a->W * a->Cin * 2 >= (1u << 31)) return V3A_ERR_SHAPE;   // 32-bit per-lane offsets inside a frame
   HaloP P = {};
   P.g = conv_gemm_params(a);
   P.x = (const char*)a->x; P.w = (const char*)a->w_halo;
   P.T = a->oT; P.H = a->oH; P.W = a->oW;
   P.cH = a->H; P.cW = a->W; P.Cin = a->Cin;
-  P.kT = kT; P.ups = a->ups2 ? 1 : 0;
+  P.kT = kT; P.ups = a->ups2 ? 1 : 0; P.inhalo = inhalo;
   P.tilesH = a->oH / TH; P.tilesW = a->oW / TW; P.nN = a->Cout / BN;
   if (!g_attr_set) {
     if (hipFuncSetAttribute((const void*)conv_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) != hipSuccess)
@@ -270,10 +290,6 @@ int v3a_conv_halo_launch(const v3a_conv_args* a, void* stream) {
 
 // number of tiles the halo kernel would launch for this layer (0 = not eligible): the dispatcher uses it only for layers that fill the chip
 extern "C" long v3a_conv_halo_tiles(const v3a_conv_args* a) {
-  if (!a || !a->w_halo || (a->halo_kT != 1 && a->halo_kT != 3)) return 0;
-  if (a->sT != 1 || a->sH != 1 || a->sW != 1 || a->pH != 1 || a->pW != 1 || a->pT != a->halo_kT - 1 || a->replicate) return 0;
-  if (a->Cin % CK || a->Cout % BN || a->oH % TH || a->oW % TW) return 0;
-  const int eH = a->ups2 ? 2 * a->H : a->H, eW = a->ups2 ? 2 * a->W : a->W;
-  if (a->oH != eH || a->oW != eW || a->oT != a->T || a->out_row_group > 0 || (a->flags & V3A_GEMM_SCALE_PER_BATCH)) return 0;
+  if (!a || !a->w_halo || !halo_form(a)) return 0;
   return (long)a->oT * (a->oH / TH) * (a->oW / TW) * (a->Cout / BN);
 }

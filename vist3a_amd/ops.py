@@ -286,13 +286,18 @@ def conv(
     stride=(1, 1, 1), pad=(0, 0, 0), out_size=None, ups2: bool = False, replicate: bool = False,
     act: int = L.ACT_NONE, residual: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
     out_f32: bool = False, tile: int = -1, residual2: Optional[torch.Tensor] = None, res_row_mod: int = 0,
-    relu_out: bool = False, out_rows: Optional[tuple] = None,
+    relu_out: bool = False, out_rows: Optional[tuple] = None, form_scale: Optional[float] = None,
 ) -> torch.Tensor:
     """x: channels-last [T,H,W,CinP] bf16 contiguous -> out [oT,oH,oW,CoutP].  pad = LEADING pad per dim.  Spatial
     dims follow PyTorch's symmetric-pad formula; the temporal dim is causal (all padding leading) when
     pad_T == k_T - 1 and symmetric otherwise.  `out_size` overrides.
     tile: -1 = automatic (the halo-tile kernel for wide 3x3(x3) layers, else the implicit GEMM with a heuristic tile), >= 0 = that
-    implicit-GEMM tile, -2 = force the halo-tile kernel (error if the layer is not of its form), -3 = never the halo-tile kernel."""
+    implicit-GEMM tile, -2 = force the halo-tile kernel (error if the layer is not of its form), -3 = never the halo-tile kernel.
+    An H-STRIP of a spatially sharded image carries one explicit halo row above and below (the neighbours' boundary rows, zeros at the image
+    border) and is convolved VALID in H: pad = (pT, 0, pW) with out_size = (T, H - 2, W) - or, with ups2, pad = (pT, -1, pW) and out_size =
+    (T, 2 (H - 2), 2 W) - both forms of the halo-tile kernel as well (v3a_conv_args).
+    form_scale (with tile = -1): choose halo-tile vs implicit GEMM as if the layer were form_scale times larger - a rank's strip takes the
+    kernel form the whole image would take, which keeps a sharded decode bit-identical to the unsharded one."""
     if x.dim() != 4 or not x.is_contiguous() or x.dtype != bf16 or not x.is_cuda:
         raise ValueError("x must be a contiguous device bf16 tensor [T,H,W,C]")
     T, H, W, Cin = x.shape
@@ -332,6 +337,8 @@ def conv(
         *(out_rows if out_rows is not None else (0, 0, 0)),
         _ptr(cw.w_halo), kT if cw.w_halo is not None else 0,
     )
+    if form_scale is not None and tile == -1 and cw.w_halo is not None:
+        args.tile = -2 if L.load().v3a_conv_halo_tiles(C.byref(args)) * form_scale >= 512 else -3
     L.check(L.load().v3a_conv_bf16(C.byref(args), _stream()), "v3a_conv_bf16")
     return out
 

@@ -79,7 +79,11 @@ class Text23DGS:
                         latents=latents, generator=generator, output_type="latent")["frames"]
         lat = denormalize_latents(lat)
         e1 = ev()
-        clip_cl = self.vae.decode_cl(lat)
+        wg = getattr(self.pipe.plan, "world", None) if self.pipe.plan is not None else None
+        if wg is not None and wg.world > 1 and lat.shape[3] % wg.world == 0:
+            clip_cl = self.vae.decode_cl_sharded(lat, wg)      # one clip over the ranks of the scene: H-strips with exchanged halo rows
+        else:
+            clip_cl = self.vae.decode_cl(lat)
         ff_cl = ops.bilinear_cl(clip_cl, (self.ff_res, self.ff_res), align_corners=False)
         e2 = ev()
         out = self.stitched_decoder.forward_with_latent(lat, None, train=False, image_cl=ff_cl)

@@ -163,6 +163,75 @@ class WanVAEDecoder:
             x = y
         return ops.conv(x, rs, pad=(0, 1, 1), ups2=True)
 
+    # ------------------------------------------------------------------ one clip over several ranks: H-strips with exchanged halo rows
+    @staticmethod
+    def _with_halo(n: torch.Tensor, group) -> torch.Tensor:
+        """strip [T,h,W,C] -> [T,h+2,W,C]: the bottom row of the strip above and the top row of the strip below (zeros at the image
+        border = the convolution's zero padding), exchanged in ONE small all-gather of every rank's two boundary rows"""
+        P, r = group.world, group.rank
+        T, h, W, C = n.shape
+        edge = torch.stack([n[:, 0], n[:, -1]], 0).contiguous()
+        gb = torch.empty(P, edge.numel(), device=n.device, dtype=n.dtype)
+        group.all_gather(gb, edge).wait()
+        zero = torch.zeros(T, 1, W, C, device=n.device, dtype=n.dtype)
+        top = gb[r - 1].view(2, T, 1, W, C)[1] if r > 0 else zero
+        bot = gb[r + 1].view(2, T, 1, W, C)[0] if r < P - 1 else zero
+        return torch.cat([top, n, bot], 1)
+
+    def _res_strip(self, rb: "_Res", x: torch.Tensor, group) -> torch.Tensor:
+        T, h, W, _ = x.shape
+        P = float(group.world)
+        h0 = x if rb.sc is None else ops.conv(x, rb.sc)
+        n = ops.rownorm_act(x, rb.g1, mode=1, act=L.ACT_SILU)
+        y = ops.conv(self._with_halo(n, group), rb.c1, pad=(2, 0, 1), out_size=(T, h, W), form_scale=P)
+        n = ops.rownorm_act(y, rb.g2, mode=1, act=L.ACT_SILU)
+        return ops.conv(self._with_halo(n, group), rb.c2, pad=(2, 0, 1), out_size=(T, h, W), residual=h0, form_scale=P)
+
+    @torch.no_grad()
+    def decode_cl_sharded(self, z: torch.Tensor, group) -> torch.Tensor:
+        """`decode_cl` of ONE clip over the `group.world` ranks of a scene-parallel run: the latent-resolution part (conv_in, the
+        mid block with its per-frame attention over all positions: 3 % of the decoder's FLOPs) runs replicated, then every rank owns an
+        H-STRIP of the image through the four up blocks.  A 3x3 convolution needs one row of its neighbours' strips: before each one the ranks
+        all-gather their two boundary rows (<= 1.3 MB per rank, 30 exchanges per clip) and convolve the haloed strip VALID in H - the same
+        kernels, tap order and k-order as the unsharded decode, so the strips are bit-identical to the rows of `decode_cl`
+        (tests/test_vae_gpu.py::test_strip_sharded_decode_is_bit_identical).  The temporal dimension is not split (causal convolutions look
+        back over the whole clip).  Every rank returns the full clip [T, 8h, 8w, 8]."""
+        P, r = group.world, group.rank
+        if z.dim() != 5 or z.shape[0] != 1:
+            raise ValueError("expected z [1, z_dim, T, h, w]")
+        x = z[0].permute(1, 2, 3, 0).to(device=self.device, dtype=bf16).contiguous()
+        x = ops.conv(x, self.pq)
+        x = ops.conv(x, self.conv_in, pad=(2, 1, 1))
+        x = self.mid1(self.attn(self.mid0(x)))
+        H0 = x.shape[1]
+        if P == 1 or H0 % P:
+            raise ValueError(f"{H0} latent rows do not split into {P} strips")
+        rows = H0 // P
+        x = x[:, r * rows:(r + 1) * rows].contiguous()
+        for res, mode, rs, tc, C in self.ups:
+            for rb in res:
+                x = self._res_strip(rb, x, group)
+            if mode is None:
+                continue
+            T = x.shape[0]
+            if mode == "upsample3d" and T > 1:     # time_conv: kernel (3,1,1), no spatial extent - local (see _upsample)
+                HW = x.shape[1] * x.shape[2]
+                y = torch.empty((1 + 2 * (T - 1), *x.shape[1:]), device=x.device, dtype=bf16)
+                y[0] = x[0]
+                for half, tch in enumerate(tc):
+                    ops.conv(x[1:], tch, pad=(2, 0, 0), out=y, out_rows=(HW, HW, (1 + half) * HW))
+                x = y
+            T, h, W, _ = x.shape
+            # nearest-exact 2x upsample fused into the conv's gather: the haloed strip is stored at the input resolution, output row j of the
+            # 2h-row strip reads upsampled rows j + 1 + dh of the 2 (h + 2)-row upsampled haloed strip (pad_H = -1)
+            x = ops.conv(self._with_halo(x, group), rs, pad=(0, -1, 1), ups2=True, out_size=(T, 2 * h, 2 * W), form_scale=float(P))
+        n = ops.rownorm_act(x, self.g_out, mode=1, act=L.ACT_SILU)
+        T, h, W, _ = x.shape
+        y = ops.conv(self._with_halo(n, group), self.conv_out, pad=(2, 0, 1), out_size=(T, h, W), form_scale=float(P)).clamp_(-1.0, 1.0)
+        gb = torch.empty(P, y.numel(), device=y.device, dtype=y.dtype)
+        group.all_gather(gb, y.contiguous()).wait()
+        return gb.view(P, T, h, W, y.shape[-1]).permute(1, 0, 2, 3, 4).reshape(T, P * h, W, y.shape[-1]).contiguous()
+
     @torch.no_grad()
     def decode_cl(self, z: torch.Tensor) -> torch.Tensor:
         """Same decode, result left channels-last [T, 8h, 8w, 8] bf16 (RGB in channels 0-2, clamped to [-1,1]) — the layout
