@@ -410,6 +410,11 @@ def main():
                                    "VAE decode, 448^2 AnySplat enc_blocks_2 reconstruction with voxel fusion; "
                                    + ("one scene over all GPUs (CFG-parallel x sequence-parallel)" if coop else "1 prompt per GPU (data parallel)"),
                        "denoise_steps": a.denoise_steps, "views": a.num_frames, "dit_tokens": N, "gaussians_last_scene": U,
+                       "precision": {"dit / vae / recon backbone": "bf16 MFMA, fp32 accumulate (the reference's autocast dtype)",
+                                     "camera head": "fp32",
+                                     "depth + gaussian DPT heads": ("fp32-equivalent (split-bf16 MFMA: 3 products, fp32 accumulate, fp32 activations as bf16 pairs) - the reference "
+                                                                    "runs them with autocast off" if model.stitched_decoder.stitched_3d_model.engine().cfg.dpt_precision == "f32"
+                                                                    else "bf16 (opt-in deviation)")},
                        **({"per_rank_last_scene": per_rank, "rccl": rccl_info} if per_rank else {}),
                        **({"scene_parallel": {
                            "layout": dict(zip(("cfg_degree", "sp_degree"), DenoisePlan.layout(world))),

@@ -817,6 +817,14 @@ def test_gemm_row_sumsq_by_product_is_tile_independent(hip_lib):
             assert ((sq - want).abs() / want).max().item() < 1e-5
         assert torch.equal(out, ref_out) and torch.equal(sq, ref_sq), names[t]
     assert torch.equal(ops.gemm(a, w, bias), ref_out)     # and the by-product does not disturb the output
+    # the statistics describe bf16(acc + bias) only: any epilogue stage behind it is refused, not silently mis-described
+    sq = torch.zeros(M, N // 32, device=dev)
+    from vist3a_amd import lib as L
+    for kw in (dict(residual=ref_out), dict(relu_out=True), dict(act=L.ACT_RELU), dict(out=torch.empty(2 * M, N, device=dev, dtype=bf16), out_rows=(64, 64, 0))):
+        with pytest.raises(ValueError):
+            ops.gemm(a, w, bias, row_sumsq=sq, **kw)
+    with pytest.raises(ValueError):     # batched problems write batch * M rows of statistics
+        ops.gemm(a, w, bias, row_sumsq=sq, batch=(2, 0, 0, M * N), out=torch.empty(2 * M, N, device=dev, dtype=bf16))
 
 
 @pytest.mark.parametrize("name,B,H,Nq,Nk,Lkp,biased", XATTN_CASES, ids=[c[0] for c in XATTN_CASES])

@@ -872,7 +872,9 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   p.act = a->act; p.flags = a->flags;
   p.res2 = (const char*)a->residual2; p.ldr2 = a->ldr2; p.res_mod = a->res_row_mod;
   if (a->row_sumsq) {   // by-product of the plain bias epilogue only: the squares are those of bf16(acc + bias)
-    if (a->N % 32 || a->act != V3A_ACT_NONE || a->scale || a->split_k > 1 || (a->flags & V3A_GEMM_BIAS_ROW)) return V3A_ERR_ARG;
+    // (... and of nothing else: with a residual, a ReLU or a row scatter the statistics would not describe what is stored)
+    if (a->N % 32 || a->act != V3A_ACT_NONE || a->scale || a->split_k > 1 || (a->flags & (V3A_GEMM_BIAS_ROW | V3A_GEMM_RELU_OUT)) ||
+        a->residual || a->residual2 || a->out_row_group > 0) return V3A_ERR_ARG;
     p.rowsq = a->row_sumsq;
   }
   p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;

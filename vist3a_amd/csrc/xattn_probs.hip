@@ -191,6 +191,8 @@ extern "C" int v3a_xattn_probs_bf16(const v3a_xattn_probs_args* a, void* stream)
   p.scale_log2e = a->scale * 1.4426950408889634f;
   if (a->q_row_sumsq) {
     if (a->q_sumsq_parts <= 0 || a->q_sumsq_parts % 4) return V3A_ERR_SHAPE;
+    // the statistics are indexed by the DENSE row number b * Nq + m of the projection that produced q
+    if (a->B > 1 && a->q_batch_stride != (long)a->Nq * a->ldq) return V3A_ERR_SHAPE;
     p.qsq = a->q_row_sumsq; p.qparts = a->q_sumsq_parts; p.q_eps = a->q_eps; p.inv_dim = 1.0f / (float)(a->H * 128);
   }
   const int nu = (a->Lkp + 31) / 32;   // sub-tiles over the PADDED row: every column of [0, Lkp) is written (zeros beyond the last key)

@@ -154,8 +154,11 @@ def gemm(
         *(out_rows if out_rows is not None else (0, 0, 0)),
     )
     if row_sumsq is not None:
-        if a_scale is not None or row_sumsq.dtype != f32 or not row_sumsq.is_contiguous() or row_sumsq.numel() < M * (N // 32) or N % 32:
-            raise ValueError("row_sumsq must be contiguous f32 [M, N // 32] (bf16 GEMM, N % 32 == 0)")
+        nbat = int(batch[0]) if batch is not None else 1
+        if a_scale is not None or row_sumsq.dtype != f32 or not row_sumsq.is_contiguous() or row_sumsq.numel() < nbat * M * (N // 32) or N % 32:
+            raise ValueError("row_sumsq must be contiguous f32 [batch * M, N // 32] (bf16 GEMM, N % 32 == 0)")
+        if residual is not None or residual2 is not None or relu_out or out_rows is not None or act != L.ACT_NONE or scale is not None or bias_row:
+            raise ValueError("row_sumsq is a by-product of the plain bias epilogue only")
         args.row_sumsq = row_sumsq.data_ptr()
     nb = 1
     if batch is not None:
