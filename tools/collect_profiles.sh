@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=$R/gpurun_out
 mkdir -p $O
-python -m pytest tests -q -m gpu -rP --durations=12 > $O/prof_gputest_stdout.log 2>&1
+V3A_FULL_SIZE=1 python -m pytest tests -q -m gpu -rP --durations=25 > $O/prof_gputest_stdout.log 2>&1   # incl. the production-size teacher-forced runs
 tail -3 $O/prof_gputest_stdout.log
 cp $O/parity.json $O/prof_parity.json
 python bench.py 2>/dev/null | tail -1 > $O/prof_bench_default_run.json
@@ -32,5 +32,8 @@ python tools/xprobs_time.py 2>/dev/null | grep '^{' > $O/prof_xprobs_time.jsonl
 python tools/conv_sweep.py 2>/dev/null | tail -2 > $O/prof_conv_sweep.txt
 python tools/vae_time.py 2>/dev/null | tail -2 > $O/prof_vae_time.jsonl
 python tools/recon_time.py 2>/dev/null | tail -2 > $O/prof_recon_time.jsonl
+python tools/dpt_layers.py 13 f32 2>/dev/null | grep "^{" > $O/prof_dpt_layers_f32.jsonl
+python tools/dpt_layers.py 13 bf16 2>/dev/null | grep "^{" | tail -1 > $O/prof_dpt_layers_bf16_total.jsonl
+python tools/conv_split_sweep.py 2>/dev/null | grep "^{" > $O/prof_conv_split_sweep.jsonl
 for v in 1 0 1 0; do V3A_CTX_VO=$v python tools/dit_time.py 2>/dev/null | tail -1; done > $O/prof_dit_time_ctx_vo_on_off.jsonl
 ls -la $O | head -50
