@@ -227,8 +227,36 @@ torch.cuda.synchronize()
 from vist3a_amd.wan.dit import GraphedWanDiT
 gout = WanT2VPipeline(GraphedWanDiT(model, capture_sp=True), UniPCMultistepScheduler(flow_shift=5.0), plan=DenoisePlan.from_dist())(**kw)["frames"].clone()
 torch.cuda.synchronize()
+ok = bool(torch.equal(out, ref)) and bool(torch.equal(gout, ref))
+# the two stages behind the denoise, sharded over ALL ranks of the scene (round 5): VAE decode by H-strips with exchanged halo rows,
+# reconstruction by views with one K | V^T all-gather per global block - each must return the unsharded result on every rank
+wg = DenoisePlan.from_dist().world
+if wg is not None:
+    from vist3a_amd.t23d import random_vae_decoder_state_dict
+    from vist3a_amd.wan.vae import WanVAEConfig, WanVAEDecoder
+    vcfg = WanVAEConfig(base_dim=16)
+    vae = WanVAEDecoder(vcfg, random_vae_decoder_state_dict(vcfg, 1, "cuda"))
+    z = torch.randn(1, 16, 2, 16, 16, generator=g).cuda()
+    ok = ok and bool(torch.equal(vae.decode_cl_sharded(z, wg), vae.decode_cl(z)))
+    from vist3a_amd.models.anysplat_stitched import AnySplatWeights
+    from vist3a_amd.models.stitched_model import StitchVAE3D
+    from vist3a_amd.models.stitching_layer_builder import parse_conv_spec
+    from vist3a_amd.recon.engine import ReconCfg
+    from vist3a_amd.recon.weights import random_recon_state_dict
+    rk = dict(C=64, heads=1, n_dino=22, depth=24, cam_heads=2, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+    st = StitchVAE3D(None, AnySplatWeights(random_recon_state_dict(ReconCfg(**rk), seed=4, device="cuda", scene_like=True), ReconCfg(**rk)), "cuda",
+                     "enc_blocks_2", parse_conv_spec("conv3d_k5x3x3_o64_s1x2x2_p2x1x1"), resolution=64)
+    with torch.no_grad():
+        st.stitching_layer.weight.copy_(torch.randn(st.stitching_layer.weight.shape, generator=g) * 0.05)
+    lat = torch.randn(1, 16, 3, 8, 8, generator=g).cuda()
+    img = (torch.rand(1, 3, 9, 56, 56, generator=g) * 2 - 1).cuda()
+    a = st.forward_with_latent(lat, img, train=False)
+    b = st.forward_with_latent(lat, img, train=False, recon_group=wg)
+    ok = ok and bool(torch.equal(a.gaussians.means, b.gaussians.means)) and bool(torch.equal(a.depth_dict["depth"], b.depth_dict["depth"]))
+    ok = ok and bool(torch.equal(a.gaussians.harmonics, b.gaussians.harmonics)) and bool(torch.equal(a.pred_pose_enc_list[-1], b.pred_pose_enc_list[-1]))
+    torch.cuda.synchronize()
 res = [None] * dist.get_world_size()
-dist.all_gather_object(res, bool(torch.equal(out, ref)) and bool(torch.equal(gout, ref)))
+dist.all_gather_object(res, ok)
 if dist.get_rank() == 0:
     print(json.dumps(res))
 dist.destroy_process_group()
@@ -239,7 +267,8 @@ dist.destroy_process_group()
 def test_rccl_scene_parallel_denoise_matches_single_gpu(hip_lib, tmp_path, world):
     """`bench.py --parallel scene` / `inference_t23d.py --scene_parallel` in miniature over REAL ranks: one process per GPU, RCCL
     over xGMI, DenoisePlan.from_dist() (CFG-parallel x sequence-parallel, K|V^T slabs read in place) - the 4-step CFG denoise must
-    reproduce the single-GPU latents bit for bit on every rank.  Needs `world` GPUs (skipped on the 1-GPU dev box; the same
+    reproduce the single-GPU latents bit for bit on every rank, and (world > 1) the strip-sharded VAE decode and the view-sharded
+    reconstruction must return the unsharded clip / scene on every rank.  Needs `world` GPUs (skipped on the 1-GPU dev box; the same
     decomposition is covered there by the virtual-rank tests in test_dit_gpu.py and the 2-process gloo test)."""
     import os, subprocess, sys, json
     if torch.cuda.device_count() < world:

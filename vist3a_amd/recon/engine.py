@@ -149,6 +149,13 @@ class _DPT:
         self.oc1 = cw(s + "output_conv1")
         self.oc20, self.oc22 = cw(s + "output_conv2.0"), cw(s + "output_conv2.2")
         self.merger = cw("input_merger.0") if gs else None
+        if gs and split:
+            # the 7x7 image convolution (3 -> 128 channels) with its seven dw taps unrolled into channels: the 3 real channels padded to 8 make a
+            # K of 7 x 7 x 8 = 392 (x 3 products = 1176) of which 147 are real; [dw][c] = 21 -> 24 channels under a 7 x 1 kernel is K = 168 (x 3 = 504)
+            w = sd[p + "input_merger.0.weight"].detach().float()              # [co, 3, dh, dw]
+            w2 = torch.zeros(w.shape[0], 24, 7, 1)
+            w2[:, :21, :, 0] = w.permute(0, 3, 1, 2).reshape(w.shape[0], 21, 7).cpu()   # channel dw * 3 + c
+            self.merger = CW(w2, sd.get(p + "input_merger.0.bias"), device=dev)
         self.pos_cache: Dict[tuple, torch.Tensor] = {}
 
     def pos(self, C, ph, pw, W, H, dev):
@@ -404,7 +411,9 @@ class ReconEngine:
         depth, dconf, pts = ops.depth_unproject(raw, cam, S, H, W)
         q = self.gs_head
         o = self._dpt_trunk_f32(g, q, S, H, W)
-        di = cs(ops.split_f32(img), q.merger, pad=(0, 3, 3), act=R)
+        # image with the dw taps of the 7x7 kernel unrolled into channels (see _DPT): u[s, h, w, dw * 3 + c] = img[s, h, w + dw - 3, c]
+        u = torch.nn.functional.pad(img[..., :3], (0, 0, 3, 3)).unfold(2, 7, 1).permute(0, 1, 2, 4, 3).reshape(S, H, W, 21)
+        di = cs(ops.split_f32(torch.nn.functional.pad(u, (0, 3)).contiguous()), q.merger, pad=(0, 3, 0), act=R)
         up = ops.bilinear_cl_pair(o, (H, W), align_corners=True, add=di, table=q.pos(o.shape[-1], H, W, W, H, dev))
         c = cs(up, q.oc20, pad=(0, 1, 1), act=R)
         raw_gs = cs(c, q.oc22, out_f32=True).view(S * H * W, -1)
