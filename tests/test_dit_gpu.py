@@ -254,7 +254,7 @@ def test_wan14b_width_two_blocks_matches_oracle(hip_lib):
 
 
 def test_config4_14b_width_eight_blocks_match_oracle(hip_lib, parity):
-    """BASELINE config #4 (Wan-14B stitched, fp8 MFMA attention) on EIGHT of its 40 blocks, 1024 tokens per batch item, B = 2: the bf16
+    """BASELINE config #4 (Wan-14B stitched, fp8 MFMA attention) on EIGHT of its 40 blocks, 512 tokens per batch item, B = 2: the bf16
     mode against the contract oracle and the fp8-attention mode against the oracle with the e4m3 rounding points emulated - with the
     error-vs-depth curve of both, so a defect that only compounds shows."""
     from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
@@ -263,7 +263,7 @@ def test_config4_14b_width_eight_blocks_match_oracle(hip_lib, parity):
     sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=44).items()}
     model = WanDiT(WanDiTConfig(**kw), sd, device="cuda")
     g = torch.Generator().manual_seed(45)
-    lat = torch.randn(2, 16, 1, 64, 64, generator=g).to(torch.bfloat16)   # 1024 tokens per item
+    lat = torch.randn(2, 16, 1, 32, 64, generator=g).to(torch.bfloat16)   # 512 tokens per item (the oracle side: ~50 s of host time)
     text = (torch.randn(2, 96, 256, generator=g) * 0.5).to(torch.bfloat16).float()
     text[0, 60:] = 0
     text[1, 70:] = 0
