@@ -56,7 +56,7 @@ def recon_full(weights=None) -> SimpleNamespace:
         return d
 
     fp = OC.checksum(lat, img, w, b, sd["encoder.aggregator.frame_blocks.0.attn.qkv.weight"], sd["encoder.gaussian_param_head.scratch.output_conv2.2.weight"])
-    return SimpleNamespace(name="recon_full_C1024_S13", fingerprint=fp, sources=(R,), compute=compute, ocfg=ocfg, sd=sd, w=w, b=b, lat=lat, img=img, S=S, H=H)
+    return SimpleNamespace(name="recon_full_C1024_S13", fingerprint=fp, sources=(R,), case_fns=(recon_full_weights, recon_full), compute=compute, ocfg=ocfg, sd=sd, w=w, b=b, lat=lat, img=img, S=S, H=H)
 
 
 def recon_config3() -> SimpleNamespace:
@@ -85,7 +85,7 @@ def recon_config3() -> SimpleNamespace:
         return d
 
     fp = OC.checksum(lat, img, w, b, sd["encoder.aggregator.frame_blocks.0.attn.qkv.weight"])
-    return SimpleNamespace(name="recon_config3_S21_width128", fingerprint=fp, sources=(R,), compute=compute, ocfg=ocfg, sd=sd, w=w, b=b, lat=lat, img=img,
+    return SimpleNamespace(name="recon_config3_S21_width128", fingerprint=fp, sources=(R,), case_fns=(recon_config3,), compute=compute, ocfg=ocfg, sd=sd, w=w, b=b, lat=lat, img=img,
                            S=S, H=H)
 
 
@@ -111,10 +111,34 @@ def dit_full_depth() -> SimpleNamespace:
         return d
 
     fp = OC.checksum(lat, text, sd["blocks.0.attn1.to_q.weight"], sd["blocks.29.ffn.net.2.weight"])
-    return SimpleNamespace(name="dit_full_depth_30_blocks_N4096", fingerprint=fp, sources=(O,), compute=compute, ocfg=ocfg, sd=sd, lat=lat, text=text, t=t)
+    return SimpleNamespace(name="dit_full_depth_30_blocks_N4096", fingerprint=fp, sources=(O,), case_fns=(dit_full_depth,), compute=compute, ocfg=ocfg, sd=sd, lat=lat, text=text, t=t)
 
 
-CASES = {"recon_full": recon_full, "recon_config3": recon_config3, "dit_full_depth": dit_full_depth}
-# digest name -> oracle modules whose source it depends on (what each case passes as `sources`; lets a CPU test check every committed
-# digest against the current sources without building the cases' gigabytes of weights)
-SOURCES = {"recon_full_C1024_S13": (R,), "recon_config3_S21_width128": (R,), "dit_full_depth_30_blocks_N4096": (O,)}
+def dit_config4_two_blocks() -> SimpleNamespace:
+    """BASELINE config #4 at size - Wan-14B width, the CFG pair of a 13-view scene (B = 2, 4096 tokens), two blocks:
+    tests/test_dit_gpu.py::test_config4_wan14b_two_blocks_at_4096_tokens_matches_oracle"""
+    ocfg = O.WanDiTConfig(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=2, text_dim=512, freq_dim=256)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=4).items()}
+    g = torch.Generator().manual_seed(44)
+    lat = torch.randn(2, 16, 4, 64, 64, generator=g).to(torch.bfloat16)
+    text = (torch.randn(2, 512, 512, generator=g) * 0.5).to(torch.bfloat16).float()
+    text[0, 64:] = 0
+    text[1, 80:] = 0
+    t = torch.tensor([611, 611])
+
+    def compute():
+        t0 = time.time()
+        ref16 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True)
+        t1 = time.time()
+        ref8 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, flash=True, merge_padding=True, ctx_vo=True, num_layers=1)
+        return dict(ref16=ref16, ref8=ref8, seconds_bf16_two_blocks=t1 - t0, seconds_fp8_one_block=time.time() - t1)
+
+    fp = OC.checksum(lat, text, sd["blocks.0.attn1.to_q.weight"], sd["blocks.1.ffn.net.2.weight"])
+    return SimpleNamespace(name="dit_config4_14B_two_blocks_N4096_B2", fingerprint=fp, sources=(O,), case_fns=(dit_config4_two_blocks,), compute=compute, ocfg=ocfg, sd=sd, lat=lat, text=text, t=t)
+
+
+CASES = {"recon_full": recon_full, "recon_config3": recon_config3, "dit_full_depth": dit_full_depth, "dit_config4_two_blocks": dit_config4_two_blocks}
+# digest name -> (oracle modules, case functions) whose source it depends on (what each case passes as `sources` / `case_fns`; lets a CPU
+# test check every committed digest against the current sources without building the cases' gigabytes of weights)
+SOURCES = {"recon_full_C1024_S13": ((R,), (recon_full_weights, recon_full)), "recon_config3_S21_width128": ((R,), (recon_config3,)),
+           "dit_full_depth_30_blocks_N4096": ((O,), (dit_full_depth,)), "dit_config4_14B_two_blocks_N4096_B2": ((O,), (dit_config4_two_blocks,))}

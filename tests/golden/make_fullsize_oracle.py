@@ -30,6 +30,6 @@ if __name__ == "__main__":
     for name in a.cases or list(FC.CASES):
         t0 = time.time()
         c = FC.CASES[name]()
-        _, live = OC.oracle(c.name, c.fingerprint, c.compute, sources=c.sources)
+        _, live = OC.oracle(c.name, c.fingerprint, c.compute, sources=c.sources, case_fns=c.case_fns)
         assert live
         print(f"{name}: oracle_{c.name}.safetensors written to {a.out} in {time.time() - t0:.0f} s ({torch.get_num_threads()} threads)", flush=True)

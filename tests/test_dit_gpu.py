@@ -447,7 +447,7 @@ def test_full_depth_production_size_forward_matches_oracle(hip_lib, parity):
     out = outs[30]
     torch.cuda.synchronize()
     # (the two 30-block oracle forwards take ~2 minutes of host time: committed digest, tests/oracle_cache.py)
-    od, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources)
+    od, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources, case_fns=case.case_fns)
     r, rc, floor = OC.rel(out, od["ref"]), OC.rel(out, od["ref_c"]), OC.rel_dd(od["ref_c"], od["ref"])
     curve = {L: OC.rel(outs[L], od[f"depth{L}"]) for L in depths}
     mx = (OC.digest(out) - od["ref"]).abs().max().item()
@@ -607,35 +607,25 @@ def test_config4_wan14b_two_blocks_at_4096_tokens_matches_oracle(hip_lib, parity
     (N = 4096 tokens, M = 8192 GEMM rows: the ragged 5120 / 13824 tilings at their real M), 512-row zero-padded prompts - two blocks
     in bf16 against the oracle with the kernel contracts emulated (bf16 rounding points, bf16-P flash tiles, merged padding key),
     and one block in the config's fp8-attention mode against the oracle with the e4m3 rounding points."""
-    import time
     from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
-    kw = dict(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=2, text_dim=512, freq_dim=256)
-    ocfg = O.WanDiTConfig(**kw)
-    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=4).items()}
-    model = WanDiT(WanDiTConfig(**kw), sd, device="cuda")
-    g = torch.Generator().manual_seed(44)
-    lat = torch.randn(2, 16, 4, 64, 64, generator=g).to(torch.bfloat16)
-    text = (torch.randn(2, 512, 512, generator=g) * 0.5).to(torch.bfloat16).float()
-    text[0, 64:] = 0
-    text[1, 80:] = 0
-    t = torch.tensor([611, 611])
+    import fullsize_cases as FC
+    import oracle_cache as OC
+    case = FC.dit_config4_two_blocks()
+    ocfg, sd, lat, text, t = case.ocfg, case.sd, case.lat, case.text, case.t
+    model = WanDiT(WanDiTConfig(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=2, text_dim=512, freq_dim=256), sd, device="cuda")
     out16 = model(lat.cuda(), t.cuda(), text.cuda())[0].float().cpu()
     out16_1 = model(lat.cuda(), t.cuda(), text.cuda(), num_layers=1)[0].float().cpu()
     model.attn_dtype = "fp8"
     out8 = model(lat.cuda(), t.cuda(), text.cuda(), num_layers=1)[0].float().cpu()    # the fp8 mode on ONE block (half the oracle time)
     model.attn_dtype = "bf16"
     torch.cuda.synchronize()
-    t0 = time.time()
-    with torch.no_grad():
-        ref16 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True)
-        t1 = time.time()
-        ref8 = O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, flash=True, merge_padding=True, ctx_vo=True, num_layers=1)
-    t2 = time.time()
-    r16, r8, shift = _rel(out16, ref16), _rel(out8, ref8), _rel(out8, out16_1)
+    # (the two oracle forwards take 85 + 53 s of host time: committed digest, tests/oracle_cache.py)
+    od, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources, case_fns=case.case_fns)
+    r16, r8, shift = OC.rel(out16, od["ref16"]), OC.rel(out8, od["ref8"]), _rel(out8, out16_1)
     parity("dit_config4_14B_N4096_B2_two_blocks", rel_bf16_vs_contract_oracle=r16, rel_fp8_attention_vs_e4m3_oracle=r8,
-           fp8_attention_mode_vs_bf16_mode=shift, oracle_seconds=[t1 - t0, t2 - t1])
+           fp8_attention_mode_vs_bf16_mode=shift, oracle="live" if live else "digest fixture")
     print(f"config #4 at size (14B width, N=4096, B=2, 2 blocks): bf16 vs contract oracle {r16:.2e}; fp8 attention vs e4m3 oracle {r8:.2e}; "
-          f"fp8 mode moves the output by {shift:.2e}; oracle {t1 - t0:.0f} + {t2 - t1:.0f} s")
+          f"fp8 mode moves the output by {shift:.2e} ({'live' if live else 'fixture'})")
     assert out16.shape == lat.shape and torch.isfinite(out16).all() and torch.isfinite(out8).all()
     assert r16 < 6e-3 and r8 < 1.3e-2, (r16, r8)    # the N = 6144 / 1.3B-width two-block forward measured 2.6e-3; 14B width at 128 tokens 5.3e-3 / 6.3e-3
 

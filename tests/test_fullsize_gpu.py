@@ -102,7 +102,7 @@ def test_full_size_reconstruction_matches_oracle(recon_full, parity):
     eng = model.stitched_3d_model.engine()
     _, geo = eng.token_workspace(S, H, H)
     taps = [t.view(S, geo["Pp"], -1)[:, :geo["P"]].float().cpu() for t in geo["taps"]]
-    ora, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources)
+    ora, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources, case_fns=case.case_fns)
     tap_c = [OC.rel(t, ora[f"tap{i}"]) for i, t in enumerate(taps)]
     tap_32 = [OC.rel(t, ora[f"tap{i}_fp32"]) for i, t in enumerate(taps)]
     floor = [OC.rel_dd(ora[f"tap{i}"], ora[f"tap{i}_fp32"]) for i in range(len(taps))]
@@ -172,7 +172,7 @@ def test_config3_21_view_reconstruction_layout_matches_oracle(hip_lib, parity):
     eng = model.stitched_3d_model.engine()
     _, geo = eng.token_workspace(S, H, H)
     taps = [t_.view(S, geo["Pp"], -1)[:, :geo["P"]].float().cpu() for t_ in geo["taps"]]
-    od, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources)
+    od, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources, case_fns=case.case_fns)
     errs = lambda tag: dict(pose=OC.rel(eo.pred_pose_enc_list[-1], od[tag + "_pose"]), depth=OC.rel(eo.depth_dict["depth"], od[tag + "_depth"]),
                             depth_conf=OC.rel(dconf, od[tag + "_depth_conf"]), raw_gs=OC.rel(anchor, od[tag + "_raw_gs"]))
     e, ed, e32 = errs("c"), errs("d"), errs("f")

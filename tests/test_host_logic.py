@@ -410,7 +410,7 @@ def test_committed_oracle_digests_match_the_current_oracle_sources():
     for f in files:
         meta = safe_open(str(f), "pt").metadata() or {}
         name = f.stem[len("oracle_"):]
-        assert meta.get("oracle_sources_sha256") == OC.source_hash(FC.SOURCES[name]), f"{f.name} is stale: re-run tests/golden/make_fullsize_oracle.py"
+        assert meta.get("oracle_sources_sha256") == OC.source_hash(*FC.SOURCES[name]), f"{f.name} is stale: re-run tests/golden/make_fullsize_oracle.py"
         assert meta.get("generated_without_gpu") == "True", f"{f.name} was not written by the CPU-only generator"
 
 
