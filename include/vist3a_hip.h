@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 19) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 20) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -84,6 +84,13 @@ typedef struct {
                          * CONSUMER applies (v3a_xattn_probs_args.q_row_sumsq), so the normalisation pass over the output disappears.
                          * Independent of the tile shape (bit-identical for every tile); with `batch` the rows of problem z are
                          * offset by z * M. */
+  void* C_t;            /* optional TRANSPOSED TAIL (v3a_gemm_bf16_nt): output columns n >= t_col0 are written to C_t[(n - t_col0) * ldct + m] (bf16)
+                         * instead of C; columns below t_col0 go to C as usual (ldc may be t_col0).  For the fused q | k | v projection of a DiT
+                         * block (diffusers WanAttnProcessor2_0 to_q / to_k / to_v, call site /root/reference/inference_t23d.py:94-103): B =
+                         * (Wq | Wk | Wv) stacked, q | k land row-major in C and V^T - what the flash kernel reads - in C_t, as 768 tiles = three
+                         * full rounds of ONE launch.  t_col0 % 192 == 0, ldct % 8 == 0, M % 8 == 0; bias only (no act / scale / residual / row
+                         * scatter / split_k / batch / row_sumsq).  Bit-identical to the two separate GEMMs. */
+  int ldct, t_col0;
 } v3a_gemm_args;
 int v3a_gemm_bf16_nt(const v3a_gemm_args* args, void* stream);
 size_t v3a_gemm_split_workspace_bytes(int M, int N, int split_k);

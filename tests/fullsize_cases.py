@@ -137,8 +137,37 @@ def dit_config4_two_blocks() -> SimpleNamespace:
     return SimpleNamespace(name="dit_config4_14B_two_blocks_N4096_B2", fingerprint=fp, sources=(O,), case_fns=(dit_config4_two_blocks,), compute=compute, ocfg=ocfg, sd=sd, lat=lat, text=text, t=t)
 
 
-CASES = {"recon_full": recon_full, "recon_config3": recon_config3, "dit_full_depth": dit_full_depth, "dit_config4_two_blocks": dit_config4_two_blocks}
+CONFIG4_DEPTHS = (1, 2, 4, 8)
+
+
+def dit_config4_eight_blocks() -> SimpleNamespace:
+    """BASELINE config #4 on eight of its 40 blocks, 14B width, B = 2 x 512 tokens, bf16 contract and e4m3-attention oracles with their
+    error-vs-depth taps: tests/test_dit_gpu.py::test_config4_14b_width_eight_blocks_match_oracle"""
+    ocfg = O.WanDiTConfig(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=8, text_dim=256, freq_dim=256)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=44).items()}
+    g = torch.Generator().manual_seed(45)
+    lat = torch.randn(2, 16, 1, 32, 64, generator=g).to(torch.bfloat16)
+    text = (torch.randn(2, 96, 256, generator=g) * 0.5).to(torch.bfloat16).float()
+    text[0, 60:] = 0
+    text[1, 70:] = 0
+    t = torch.tensor([611, 611])
+
+    def compute():
+        taps16, taps8 = {L: None for L in CONFIG4_DEPTHS}, {L: None for L in CONFIG4_DEPTHS}
+        O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True, depth_outputs=taps16)
+        O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, merge_padding=True, ctx_vo=True, depth_outputs=taps8)
+        d = {f"bf16_depth{L}": taps16[L] for L in CONFIG4_DEPTHS}
+        d.update({f"fp8_depth{L}": taps8[L] for L in CONFIG4_DEPTHS})
+        return d
+
+    fp = OC.checksum(lat, text, sd["blocks.0.attn1.to_q.weight"], sd["blocks.7.ffn.net.2.weight"])
+    return SimpleNamespace(name="dit_config4_14B_eight_blocks", fingerprint=fp, sources=(O,), case_fns=(dit_config4_eight_blocks,), compute=compute,
+                           ocfg=ocfg, sd=sd, lat=lat, text=text, t=t)
+
+
+CASES = {"dit_config4_eight_blocks": dit_config4_eight_blocks, "recon_full": recon_full, "recon_config3": recon_config3, "dit_full_depth": dit_full_depth, "dit_config4_two_blocks": dit_config4_two_blocks}
 # digest name -> (oracle modules, case functions) whose source it depends on (what each case passes as `sources` / `case_fns`; lets a CPU
 # test check every committed digest against the current sources without building the cases' gigabytes of weights)
 SOURCES = {"recon_full_C1024_S13": ((R,), (recon_full_weights, recon_full)), "recon_config3_S21_width128": ((R,), (recon_config3,)),
-           "dit_full_depth_30_blocks_N4096": ((O,), (dit_full_depth,)), "dit_config4_14B_two_blocks_N4096_B2": ((O,), (dit_config4_two_blocks,))}
+           "dit_full_depth_30_blocks_N4096": ((O,), (dit_full_depth,)), "dit_config4_14B_two_blocks_N4096_B2": ((O,), (dit_config4_two_blocks,)),
+           "dit_config4_14B_eight_blocks": ((O,), (dit_config4_eight_blocks,))}

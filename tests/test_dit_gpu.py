@@ -234,6 +234,42 @@ def test_graph_replay_follows_a_ctx_vo_mode_flip(tiny):
         model.ctx_vo = keep
 
 
+def test_fused_qkv_projection_is_bit_identical_to_separate_launches(hip_lib):
+    """`WanDiT.fused_qkv`: q | k | V^T of every block from one GEMM launch (transposed tail) - the forward equals the two-launch form bit for
+    bit at production width and token count (two blocks, CFG batch 2), eagerly and through a hipGraph (the mode is part of the capture key)."""
+    import dataclasses
+    from vist3a_amd.wan.dit import WAN_1_3B, GraphedWanDiT, WanDiT
+    from vist3a_amd.wan.weights import random_dit_state_dict
+    cfg = dataclasses.replace(WAN_1_3B, num_layers=2, text_dim=512)
+    m = WanDiT(cfg, random_dit_state_dict(cfg, seed=0, device="cuda"))
+    g = torch.Generator().manual_seed(6)
+    lat = torch.randn(2, 16, 4, 64, 64, generator=g).to(torch.bfloat16).cuda()
+    text = (torch.randn(2, 512, 512, generator=g) * 0.1).cuda()
+    text[:, 70:] = 0
+    t = torch.tensor([650, 650]).cuda()
+    seen = []
+    from vist3a_amd import ops
+    real = ops.gemm
+    ops.gemm = lambda *a, **k: (seen.append(k.get("t_out") is not None), real(*a, **k))[1]
+    try:
+        assert m.fused_qkv
+        a = m(lat, t, text)[0].clone()
+        n_fused = sum(seen)
+        m.fused_qkv = False
+        seen.clear()
+        b = m(lat, t, text)[0].clone()
+        assert n_fused == 2 and sum(seen) == 0
+    finally:
+        ops.gemm = real
+    assert torch.equal(a, b)
+    gm = GraphedWanDiT(m)
+    for mode in (True, False, True):
+        m.fused_qkv = mode
+        assert torch.equal(gm(lat, t, text)[0], a)
+    assert len(gm._graphs) == 2
+    m.fused_qkv = True
+
+
 def test_wan14b_width_two_blocks_matches_oracle(hip_lib):
     """BASELINE config #4 geometry (Wan-14B: 40 heads x 128 = 5120 wide, FFN 13824) on two blocks: the GEMM tilings are ragged
     there (5120 / 192, 13824 / 192 are not integers) — same tolerances as the 1.3B-width forward."""
@@ -258,21 +294,17 @@ def test_config4_14b_width_eight_blocks_match_oracle(hip_lib, parity):
     mode against the contract oracle and the fp8-attention mode against the oracle with the e4m3 rounding points emulated - with the
     error-vs-depth curve of both, so a defect that only compounds shows."""
     from vist3a_amd.wan.dit import WanDiT, WanDiTConfig
-    kw = dict(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=8, text_dim=256, freq_dim=256)
-    ocfg = O.WanDiTConfig(**kw)
-    sd = {k: v.to(torch.bfloat16).float() for k, v in O.make_weights(ocfg, seed=44).items()}
-    model = WanDiT(WanDiTConfig(**kw), sd, device="cuda")
-    g = torch.Generator().manual_seed(45)
-    lat = torch.randn(2, 16, 1, 32, 64, generator=g).to(torch.bfloat16)   # 512 tokens per item (the oracle side: ~50 s of host time)
-    text = (torch.randn(2, 96, 256, generator=g) * 0.5).to(torch.bfloat16).float()
-    text[0, 60:] = 0
-    text[1, 70:] = 0
-    t = torch.tensor([611, 611])
-    depths = (1, 2, 4, 8)
-    taps16, taps8 = {L: None for L in depths}, {L: None for L in depths}
-    with torch.no_grad():
-        O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, flash=True, merge_padding=True, ctx_vo=True, depth_outputs=taps16)
-        O.dit_forward(sd, ocfg, lat.float(), t, text, emulate_bf16=True, fp8_attn=True, merge_padding=True, ctx_vo=True, depth_outputs=taps8)
+    import fullsize_cases as FC
+    import oracle_cache as OC
+    case = FC.dit_config4_eight_blocks()
+    sd, lat, text, t = case.sd, case.lat, case.text, case.t
+    model = WanDiT(WanDiTConfig(num_attention_heads=40, attention_head_dim=128, ffn_dim=13824, num_layers=8, text_dim=256, freq_dim=256), sd, device="cuda")
+    depths = FC.CONFIG4_DEPTHS
+    # (two 8-block oracle forwards at 14B width: 1-2 minutes of host time - committed digest, tests/oracle_cache.py)
+    od, live = OC.oracle(case.name, case.fingerprint, case.compute, sources=case.sources, case_fns=case.case_fns)
+    taps16 = {L: od[f"bf16_depth{L}"] for L in depths}
+    taps8 = {L: od[f"fp8_depth{L}"] for L in depths}
+    _rel = OC.rel
     c16 = {L: _rel(model(lat.cuda(), t.cuda(), text.cuda(), num_layers=L)[0], taps16[L]) for L in depths}
     model.attn_dtype = "fp8"
     c8 = {L: _rel(model(lat.cuda(), t.cuda(), text.cuda(), num_layers=L)[0], taps8[L]) for L in depths}

@@ -903,3 +903,28 @@ def test_gemm_batched_operands_equal_separate_launches(hip_lib):
     one = torch.cat([ops.gemm(wo[:, h * 128:(h + 1) * 128], v[:, h * 128:(h + 1) * 128]) for h in range(H)], 1)
     assert torch.equal(out, one)
     assert ((out.float() - ref.float()).norm() / ref.float().norm()).item() < 3e-3
+
+
+
+def test_gemm_transposed_tail_is_bit_identical_to_two_launches(hip_lib):
+    """v3a_gemm_args.C_t: the fused q | k | v projection of a DiT block - columns below t_col0 row-major into C, the rest TRANSPOSED into C_t
+    (what the flash kernel reads as V^T) - against the q | k GEMM and the V^T = Wv . X^T GEMM (bias by row) it replaces, at the production
+    shape (8192 x (3072 + 1536) x 1536: 768 tiles) and at ragged / small ones: bit for bit."""
+    from vist3a_amd import ops
+    g = torch.Generator(device=dev).manual_seed(17)
+    for (M, d, K) in ((8192, 1536, 1536), (4096, 768, 512), (1000, 192, 256), (8, 384, 64)):
+        x = torch.randn(M, K, device=dev, generator=g).to(bf16)
+        w = (torch.randn(3 * d, K, device=dev, generator=g) / math.sqrt(K)).to(bf16)
+        b = torch.randn(3 * d, device=dev, generator=g)
+        qk_ref = ops.gemm(x, w[: 2 * d], b[: 2 * d].contiguous())
+        vt_ref = torch.zeros(d, M + 64, device=dev, dtype=bf16)
+        ops.gemm(w[2 * d:], x, b[2 * d:].contiguous(), out=vt_ref[:, :M], bias_row=True)
+        qk = torch.zeros(M, 2 * d, device=dev, dtype=bf16)
+        vt = torch.zeros(d, M + 64, device=dev, dtype=bf16)
+        ops.gemm(x, w, b, out=qk, t_out=vt, t_col0=2 * d)
+        assert torch.equal(qk, qk_ref), (M, d, K)
+        assert torch.equal(vt, vt_ref), (M, d, K, (vt.float() - vt_ref.float()).abs().max().item())
+    with pytest.raises(ValueError):
+        ops.gemm(x, w, b, out=qk, t_out=vt, t_col0=100)          # not whole 192-column tiles
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, w, b, out=qk, t_out=vt, t_col0=2 * d, act=1)  # bias-only epilogue

@@ -365,7 +365,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 #endif
 constexpr int ABL = V3A_GEMM_ABL;
 
-template <int NP, bool RA, int LEAD, bool F8 = false>
+// TT = true (NP = 3, RA = true only): tiles whose columns lie at or beyond p.tcol0 are stored transposed into p.Ct (gemm_store_transposed) - a
+// separate instantiation so that the dominant symbol's code is untouched.
+template <int NP, bool RA, int LEAD, bool F8 = false, bool TT = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP pin) {
   GemmP p = pin;
   if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; if (p.res) p.res += blockIdx.y * p.rz; if (p.rowsq) p.rowsq += (size_t)blockIdx.y * p.M * (p.N / 32); }
@@ -632,6 +634,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP pin) {
     const int em = m0 + (RA ? wr * 64 : ws * 32 * NP), en = n0 + (RA ? ws * 32 * NP : wr * 64);
     if constexpr (F8) gemm_dequant<MT, NTL>(p, acc, lane, em, en);
     if constexpr (!(ABL & 32) && !(ABL & 128)) gemm_add_bias<MT, NTL>(p, acc, lane, em, en, aux);
+    if constexpr (TT) {
+      static_assert(RA && NP == 3 && !F8, "transposed tail: the 256 x 192 bf16 tile");
+      if (p.Ct && n0 >= p.tcol0) {   // (tcol0 % 192 == 0: a tile is all normal or all transposed)
+        gemm_store_transposed<MT, NTL>(p, acc, smem, wave, lane, em, en);
+        return;
+      }
+    }
     gemm_row_sumsq<MT, NTL>(p, acc, lane, em, en);
     gemm_epilogue<MT, NTL, (NTL < 3 ? 2 : NTL), (MT * NTL < 8), (ABL >> 4) & 15>(p, acc, smem, wave, lane, em, en, aux);
   }
@@ -680,7 +689,11 @@ const TileEntry kTiles[] = {
     // 12: the VAE decoder's full-resolution 96 -> 96 channel convolutions (13 x 512 x 512 pixels): no padding of N to 128; two workgroups
     //     per CU.  3.21 -> 2.84 ms per layer against 256x128 (256x96 and 2-wave forms measured 4.5 ms)
     TILE_ENTRY(128, 96, 4, 1, 64, 2),
+    // 13: tile 6 with the transposed tail (v3a_gemm_args.C_t: the fused q | k | v projection of a DiT block - 512 + 256 tiles = three full rounds
+    //     in ONE launch instead of a two-round and a one-round launch); identical to tile 6 when C_t is NULL
+    { "pp_np3_ratrue_l5_tt", 256, 192, 512, PPCfg<3>::LDS_BYTES, (gemm_fn)gemm_pp_kernel<3, true, 5, false, true>, nullptr, nullptr },
 };
+constexpr int kTileTT = 13;
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 // e4m3 forms of the ping-pong tiles (K tile = 128 elements: the same bytes per row, twice the matrix rate)
 #define PP8_ENTRY(NP, RA, LEAD)                                                                     \
@@ -708,7 +721,7 @@ int pick_tile(int M, int N, bool conv = false, int mult = 1, int act = 0) {
     if (conv && (!e.conv_fn || (i >= 9 && M > 16384))) continue;
     long tm = (M + e.BM - 1) / e.BM, tn = (N + e.BN - 1) / e.BN;
     long tiles = tm * tn * mult;   // (mult: split-K slices launched side by side)
-    const bool pp = i >= 6 && i <= 8;
+    const bool pp = i >= 6 && i <= 8;   // (13, the transposed-tail form of 6, is never an automatic choice)
     const long area = (long)e.BM * e.BN;
     int per_cu = pp ? 1 : (e.lds <= 40 * 1024 ? 4 : (e.lds <= 80 * 1024 ? 2 : 1));
     long per_busiest = (tiles + 255) / 256;                       // tiles the busiest CU gets (the dispatcher spreads workgroups)
@@ -726,7 +739,8 @@ int pick_tile(int M, int N, bool conv = false, int mult = 1, int act = 0) {
 }
 
 int launch(const GemmP& p, int ti, int conv, void* stream, int nz = 1) {   // conv: 0 GEMM, 1 convolution, 2 split-bf16 convolution
-  if (ti < 0 || ti >= kNumTiles) {
+  if (p.Ct) ti = kTileTT;
+  else if (ti < 0 || ti >= kNumTiles) {
     ti = pick_tile(p.M, p.N, conv != 0, nz, p.act);
     // split-bf16 convolutions walk a 3x longer K: a layer that cannot give every CU a big tile (the 16^2 / 32^2 levels of the DPT pyramid:
     // < 128 tiles of 256 x 256) is latency-bound per tile and wants MANY small co-resident tiles (tools/conv_split_sweep.py, 13 views:
@@ -879,6 +893,12 @@ extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {
   }
   p.orow_group = a->out_row_group; p.orow_skip = a->out_row_skip; p.orow_off = a->out_row_off;
   if (a->residual2 && (a->ldr2 % 8)) return V3A_ERR_SHAPE;
+  if (a->C_t) {   // transposed tail: plain bias epilogue on both sides of t_col0, whole 192-column tiles, 8-row pieces
+    if (a->t_col0 <= 0 || a->t_col0 % 192 || a->t_col0 >= a->N || a->ldct % 8 || a->M % 8 || a->act != V3A_ACT_NONE || a->scale || a->residual ||
+        a->residual2 || a->out_row_group > 0 || a->split_k > 1 || a->batch > 1 || a->row_sumsq ||
+        (a->flags & (V3A_GEMM_BIAS_ROW | V3A_GEMM_OUT_F32 | V3A_GEMM_RELU_OUT))) return V3A_ERR_ARG;
+    p.Ct = (char*)a->C_t; p.ldct = a->ldct; p.tcol0 = a->t_col0;
+  }
   if (a->split_k < 0 || a->batch < 0 || (a->batch > 1 && a->split_k > 1) || a->batch > 65535) return V3A_ERR_ARG;
   if (a->batch > 1) {     // equally shaped problems side by side on blockIdx.y (per-head / per-prompt operands)
     if (a->a_batch_stride % 8 || a->b_batch_stride % 8 || a->c_batch_stride % 8 || a->res_batch_stride % 8) return V3A_ERR_SHAPE;

@@ -36,6 +36,9 @@ struct GemmP {
   float* rowsq;           // optional by-product: sum of squares of every (row, 32-column block) of bf16(acc + bias), [M][N / 32] f32
   // split-bf16 convolution (CONV == 2 instantiations only): the lo planes of the (hi, lo) bf16 pairs; hi planes are A / C / res / res2
   const char* A_lo; char* C_lo; const char* res_lo; const char* res2_lo;
+  // transposed tail (gemm_pp_kernel<3, true, .., TT = true> only): output columns n >= tcol0 go to Ct[(n - tcol0) * ldct + m] (bf16) instead
+  // of C - the V^T third of a fused q | k | v projection
+  char* Ct; int ldct, tcol0;
 };
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -330,6 +333,41 @@ __device__ __forceinline__ void gemm_row_sumsq(const GemmP& p, const f32x16 (&ac
       const int m = mw0 + i * 32 + l31, n = nw + j * 32;
       if (hi == 0 && m < p.M && n < p.N) p.rowsq[(size_t)m * nb + (n >> 5)] = s;
     }
+}
+
+// Transposed store of a wave's (MT*32) x (NTL*32) tile (D^T orientation, bias already added): Ct[(n - tcol0) * ldct + m] = bf16(acc).  The wave
+// writes its tile TRANSPOSED into its private LDS region with 2-byte stores (lane (l31, hi) owns token row l31: consecutive lanes write
+// consecutive tokens of one column, 64 contiguous bytes), then reads whole columns back - MT*32 tokens = 128 contiguous bytes each at MT = 2 -
+// as 16-byte pieces and stores them coalesced.  TPITCH = 136 bytes per column: the two lane halves (columns 4 apart) land on disjoint banks.
+template <int MT, int NTL>
+__device__ __forceinline__ void gemm_store_transposed(const GemmP& p, f32x16 (&acc)[MT][NTL], char* smem, int wave, int lane, int mw0, int nw) {
+  constexpr int ROWS = MT * 32, COLS = NTL * 32, TPITCH = ROWS * 2 + 8;
+  const int hi = lane >> 5, l31 = lane & 31;
+  char* reg = smem + wave * (COLS * TPITCH);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *(unsigned short*)(reg + (j * 32 + g * 8 + hi * 4 + e) * TPITCH + (i * 32 + l31) * 2) = f32_to_bf16(acc[i][j][g * 4 + e]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  constexpr int CPC = ROWS / 8;                 // 16-byte pieces per column
+  constexpr int ITERS = COLS * CPC / 64;
+  static_assert((COLS * CPC) % 64 == 0, "transposed epilogue chunking");
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = it * 64 + lane;
+    const int c = idx / CPC, pc = idx % CPC;
+    const int n = nw + c, m = mw0 + pc * 8;
+    const u32x2 a = *(const u32x2*)(reg + c * TPITCH + pc * 16), b = *(const u32x2*)(reg + c * TPITCH + pc * 16 + 8);
+    u32x4 v;
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+    if (n < p.N && m + 8 <= p.M) *(u32x4*)(p.Ct + ((size_t)(n - p.tcol0) * p.ldct + m) * 2) = v;   // (M % 8 == 0 is required by the entry point)
+  }
 }
 
 // x -> (hi, lo) with hi = bf16(x) and lo = bf16(x - hi): x = hi + lo to 2^-17 relative (16 significand bits + the sign of lo).

@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("split_k", C.c_int), ("workspace", C.c_void_p),
         ("batch", C.c_int), ("a_batch_stride", C.c_long), ("b_batch_stride", C.c_long), ("c_batch_stride", C.c_long),
         ("res_batch_stride", C.c_long), ("row_sumsq", C.c_void_p),
+        ("C_t", C.c_void_p), ("ldct", C.c_int), ("t_col0", C.c_int),
     ]
 
 
@@ -237,7 +238,7 @@ SYMBOLS = {
 }
 
 _lib = None
-EXPECTED_ABI = 19   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
+EXPECTED_ABI = 20   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
 
 
 class HipLibraryError(RuntimeError):

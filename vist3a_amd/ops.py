@@ -89,6 +89,8 @@ def gemm(
     split_k: int = 1,
     batch: Optional[tuple] = None,
     row_sumsq: Optional[torch.Tensor] = None,
+    t_out: Optional[torch.Tensor] = None,
+    t_col0: int = 0,
 ) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T); see v3a_gemm_bf16_nt for the epilogue order.
     batch = (count, a_stride, w_stride, out_stride[, residual_stride]) in elements: `count` problems of this shape in one launch, problem z
@@ -96,6 +98,8 @@ def gemm(
     row_sumsq (f32 [M, N // 32], written): per (row, 32-column block) sum of squares of bf16(acc + bias) - the statistics of an RMS norm the
     consumer applies itself (ops.xattn_probs q_row_sumsq); plain bias epilogue only.
     out_rows=(group, skip, off) scatters output row m to m + (m//group)*skip + off (out must be given).
+    t_out / t_col0 (transposed tail): output columns n >= t_col0 go to t_out[n - t_col0, m] (bf16 [N - t_col0, >= M]) instead of `out`, which then
+    holds the first t_col0 columns only - the fused q | k | v projection: q | k row-major, V^T for the flash kernel, one launch.  Bias only.
 
     scale: f32 [N] (LayerScale) or [nbatch, N] together with rows_per_batch (AdaLN gate).
     split_k > 1 (bf16 only): K cut into split_k slices computed side by side, summed by a second launch (few output tiles, long K).
@@ -107,13 +111,17 @@ def gemm(
     N, K2 = w.shape
     if K != K2:
         raise ValueError(f"K mismatch: a {tuple(a.shape)} vs w {tuple(w.shape)}")
+    if t_out is not None:
+        _chk2d(t_out, "t_out", (bf16,))
+        if out is None or t_col0 <= 0 or t_col0 % 192 or t_col0 >= N or t_out.shape[0] < N - t_col0 or t_out.shape[1] < M or out.shape[1] < t_col0:
+            raise ValueError("t_out needs an explicit out [M, >= t_col0], 0 < t_col0 < N in whole 192-column tiles, t_out [N - t_col0, >= M]")
     if out is None:
         if out_rows is not None:
             raise ValueError("out_rows needs an explicit out tensor")
         out = torch.empty((M, N), device=a.device, dtype=f32 if out_f32 else bf16)
     _chk2d(out, "out", (f32,) if out_f32 else (bf16,))
     # weight-streaming shapes (<= 128 rows against a big matrix) go to the skinny kernel: the tile GEMM would occupy N/128 CUs
-    plain = split_k <= 1 and batch is None and row_sumsq is None and a_scale is None and scale is None and residual2 is None and out_rows is None and not relu_out and tile < 0 and res_row_mod == 0
+    plain = t_out is None and split_k <= 1 and batch is None and row_sumsq is None and a_scale is None and scale is None and residual2 is None and out_rows is None and not relu_out and tile < 0 and res_row_mod == 0
     if plain and K % 512 == 0 and K >= 1024:
         if M <= 128 and N >= 512 and not bias_row:
             return _gemm_skinny(a, w, bias, out, act, residual, out_f32, transposed=False)
@@ -153,6 +161,10 @@ def gemm(
         _ptr(residual2), residual2.stride(0) if residual2 is not None else 0, res_row_mod,
         *(out_rows if out_rows is not None else (0, 0, 0)),
     )
+    if t_out is not None:
+        if a_scale is not None:
+            raise ValueError("t_out applies to the bf16 GEMM")
+        args.C_t, args.ldct, args.t_col0 = t_out.data_ptr(), t_out.stride(0), t_col0
     if row_sumsq is not None:
         nbat = int(batch[0]) if batch is not None else 1
         if a_scale is not None or row_sumsq.dtype != f32 or not row_sumsq.is_contiguous() or row_sumsq.numel() < nbat * M * (N // 32) or N % 32:
@@ -193,7 +205,7 @@ def gemm(
             pr.flops += 2.0 * M * N * K
         return out
     pr = _probe
-    if pr is not None and pr.active and not pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile_act(M, N, act)) == pr.tile and pr.take():
+    if t_out is None and pr is not None and pr.active and not pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile_act(M, N, act)) == pr.tile and pr.take():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")

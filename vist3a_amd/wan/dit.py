@@ -149,6 +149,9 @@ class WanDiT:
         # with K = heads * padded keys (1152 at Wan-1.3B) replace the flash kernel's P.V MFMAs and the K = d to_out projection.  Taken when
         # head_dim = 128, the (merged) key count is <= 128 and the block GEMMs run in bf16; False = flash attention + to_out GEMM.
         self.ctx_vo = True
+        # q | k | V^T of a block's self-attention from ONE GEMM launch (transposed tail, csrc/gemm_bf16.hip tile 13) instead of a q | k and a V^T
+        # launch: bit-identical, 117.5 -> ~105 us per block at 1.3B (three full rounds instead of 2 + 1).  False = the two launches.
+        self.fused_qkv = True
         self._load(state_dict)
 
     def _sp_ksplit(self, M: int, N: int, K: int) -> int:
@@ -204,9 +207,12 @@ class WanDiT:
         for i in range(cfg.num_layers):
             p = f"blocks.{i}."
             b = {}
-            b["wqk"] = torch.cat([W(p + "attn1.to_q.weight"), W(p + "attn1.to_k.weight")], 0).contiguous()
-            b["bqk"] = torch.cat([Fv(p + "attn1.to_q.bias"), Fv(p + "attn1.to_k.bias")], 0).contiguous()
-            b["wv"], b["bv"] = W(p + "attn1.to_v.weight"), Fv(p + "attn1.to_v.bias")
+            # to_q | to_k | to_v stacked: ONE tensor, so that the fused projection (v3a_gemm_args.C_t: q | k row-major, V^T transposed, 768
+            # tiles = three full rounds of one launch) and the separate q | k / V^T GEMMs of the sharded and e4m3 paths read the same memory
+            b["wqkv"] = torch.cat([W(p + "attn1.to_q.weight"), W(p + "attn1.to_k.weight"), W(p + "attn1.to_v.weight")], 0).contiguous()
+            b["bqkv"] = torch.cat([Fv(p + "attn1.to_q.bias"), Fv(p + "attn1.to_k.bias"), Fv(p + "attn1.to_v.bias")], 0).contiguous()
+            b["wqk"], b["bqk"] = b["wqkv"][: 2 * d], b["bqkv"][: 2 * d]
+            b["wv"], b["bv"] = b["wqkv"][2 * d:], b["bqkv"][2 * d:]
             b["wo"], b["bo"] = W(p + "attn1.to_out.0.weight"), Fv(p + "attn1.to_out.0.bias")
             b["nq"], b["nk"] = Fv(p + "attn1.norm_q.weight"), Fv(p + "attn1.norm_k.weight")
             b["n2w"], b["n2b"] = Fv(p + "norm2.weight"), Fv(p + "norm2.bias")
@@ -408,8 +414,14 @@ class WanDiT:
             # --- self attention
             norm(scale=m[:, 1], shift=m[:, 0], rows_per_batch=Nl)
             if P == 1:
-                lin(ws.n, b, "wqk", b["bqk"], out=ws.qk)
-                if g8:   # V^T = Wv . X^T: the weight rows are the GEMM's A side
+                fused_qkv = self.fused_qkv and not g8 and vbs == N and (2 * d) % 192 == 0 and Ml % 8 == 0
+                if fused_qkv:
+                    ops.gemm(ws.n, b["wqkv"], b["bqkv"], out=ws.qk, t_out=ws.vt, t_col0=2 * d)
+                else:
+                    lin(ws.n, b, "wqk", b["bqk"], out=ws.qk)
+                if fused_qkv:
+                    pass
+                elif g8:   # V^T = Wv . X^T: the weight rows are the GEMM's A side
                     for bi in range(B if vbs != N else 1):
                         r0, r1 = (0, Ml) if vbs == N else (bi * N, (bi + 1) * N)
                         ops.gemm(b["wv8"], ws.a8[r0:r1], b["bv"], out=ws.vt if vbs == N else ws.vt[:, bi * vbs: bi * vbs + N], bias_row=True,
@@ -609,7 +621,7 @@ class GraphedWanDiT:
         lk = self.dit._context(text)[5]  # eager: refreshes the persistent K / V^T buffers when the prompt changed
         d = self.dit   # the precision modes are baked into a capture: a flipped mode must not replay the old-precision graph
         key = (tuple(hidden_states.shape), tuple(text.shape), lk, threading.get_ident(), d.attn_dtype, d.gemm_dtype, tuple(d.fp8_scales),
-               d.merge_padding_keys, d.ctx_vo, None if sp is None else (id(sp), sp.world, sp.rank, d.sp_kv_split))
+               d.merge_padding_keys, d.ctx_vo, d.fused_qkv, None if sp is None else (id(sp), sp.world, sp.rank, d.sp_kv_split))
         ent = self._graphs.get(key)
         if ent is None:
             sx = torch.empty(hidden_states.shape, device=self.device, dtype=bf16)
