@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=$R/gpurun_out
 mkdir -p $O
-V3A_FULL_SIZE=1 python -m pytest tests -q -m gpu -rP --durations=25 > $O/prof_gputest_stdout.log 2>&1   # incl. the production-size teacher-forced runs
+V3A_FULL_SIZE=${V3A_FULL_SIZE:-0} python -m pytest tests -q -m gpu -rP --durations=25 > $O/prof_gputest_stdout.log 2>&1   # incl. the production-size teacher-forced runs
 tail -3 $O/prof_gputest_stdout.log
 cp $O/parity.json $O/prof_parity.json
 python bench.py 2>/dev/null | tail -1 > $O/prof_bench_default_run.json
