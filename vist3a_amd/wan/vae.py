@@ -148,20 +148,25 @@ class WanVAEDecoder:
         return video if return_dict else (video,)
 
     @staticmethod
-    def _upsample(x: torch.Tensor, mode: str, rs, tc) -> torch.Tensor:
-        """WanResample upsample2d / upsample3d (wan_utils.py:202-330) on a channels-last clip [T,H,W,C]"""
+    def _time_upsample(x: torch.Tensor, mode: str, tc) -> torch.Tensor:
+        """the temporal half of WanResample upsample3d (wan_utils.py:260-300): frames doubled by time_conv, the first frame bypassing it"""
         T = x.shape[0]
-        if mode == "upsample3d" and T > 1:
-            # time_conv emits 2C channels per frame t >= 1: the first C are frame 2t-1, the last C frame 2t of the doubled clip.  Two
-            # convolutions over the halves of the output channels write those frames in place (row scatter of the GEMM epilogue:
-            # pixel m of frame t-1 -> frame 1 + 2(t-1) + half) instead of one convolution plus two strided interleave copies.
-            HW = x.shape[1] * x.shape[2]
-            y = torch.empty((1 + 2 * (T - 1), *x.shape[1:]), device=x.device, dtype=bf16)
-            y[0] = x[0]
-            for half, tch in enumerate(tc):
-                ops.conv(x[1:], tch, pad=(2, 0, 0), out=y, out_rows=(HW, HW, (1 + half) * HW))
-            x = y
-        return ops.conv(x, rs, pad=(0, 1, 1), ups2=True)
+        if mode != "upsample3d" or T <= 1:
+            return x
+        # time_conv emits 2C channels per frame t >= 1: the first C are frame 2t-1, the last C frame 2t of the doubled clip.  Two
+        # convolutions over the halves of the output channels write those frames in place (row scatter of the GEMM epilogue:
+        # pixel m of frame t-1 -> frame 1 + 2(t-1) + half) instead of one convolution plus two strided interleave copies.
+        HW = x.shape[1] * x.shape[2]
+        y = torch.empty((1 + 2 * (T - 1), *x.shape[1:]), device=x.device, dtype=bf16)
+        y[0] = x[0]
+        for half, tch in enumerate(tc):
+            ops.conv(x[1:], tch, pad=(2, 0, 0), out=y, out_rows=(HW, HW, (1 + half) * HW))
+        return y
+
+    @classmethod
+    def _upsample(cls, x: torch.Tensor, mode: str, rs, tc) -> torch.Tensor:
+        """WanResample upsample2d / upsample3d (wan_utils.py:202-330) on a channels-last clip [T,H,W,C]"""
+        return ops.conv(cls._time_upsample(x, mode, tc), rs, pad=(0, 1, 1), ups2=True)
 
     # ------------------------------------------------------------------ one clip over several ranks: H-strips with exchanged halo rows
     @staticmethod
@@ -213,14 +218,7 @@ class WanVAEDecoder:
                 x = self._res_strip(rb, x, group)
             if mode is None:
                 continue
-            T = x.shape[0]
-            if mode == "upsample3d" and T > 1:     # time_conv: kernel (3,1,1), no spatial extent - local (see _upsample)
-                HW = x.shape[1] * x.shape[2]
-                y = torch.empty((1 + 2 * (T - 1), *x.shape[1:]), device=x.device, dtype=bf16)
-                y[0] = x[0]
-                for half, tch in enumerate(tc):
-                    ops.conv(x[1:], tch, pad=(2, 0, 0), out=y, out_rows=(HW, HW, (1 + half) * HW))
-                x = y
+            x = self._time_upsample(x, mode, tc)      # time_conv: kernel (3,1,1), no spatial extent - local to the strip
             T, h, W, _ = x.shape
             # nearest-exact 2x upsample fused into the conv's gather: the haloed strip is stored at the input resolution, output row j of the
             # 2h-row strip reads upsampled rows j + 1 + dh of the 2 (h + 2)-row upsampled haloed strip (pad_H = -1)
