@@ -24,8 +24,8 @@ if str(ROOT) not in sys.path:
 import torch
 
 # tile name (v3a_gemm_tile_name) -> kernel symbol as rocprofv3 prints it
-SYMBOL_OF_TILE = {"pp_np3_ratrue_l5": "gemm_pp_kernel<3, true, 5, false>", "pp_np3_rafalse_l5": "gemm_pp_kernel<3, false, 5, false>",
-                  "pp_np4_ratrue_l7": "gemm_pp_kernel<4, true, 7, false>"}
+SYMBOL_OF_TILE = {"pp_np3_ratrue_l5": "gemm_pp_kernel<3, true, 5, false, false>", "pp_np3_rafalse_l5": "gemm_pp_kernel<3, false, 5, false, false>",
+                  "pp_np4_ratrue_l7": "gemm_pp_kernel<4, true, 7, false, false>", "pp_np3_ratrue_l5_tt": "gemm_pp_kernel<3, true, 5, false, true>"}
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FP8_MFMA_PEAK_TFLOPS = 5000.0   # dense fp8 (--dtype fp8 only)
 

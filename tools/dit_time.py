@@ -10,8 +10,8 @@ cfg = WAN_1_3B
 sd = random_dit_state_dict(cfg, seed=0, device="cuda")
 m = WanDiT(cfg, sd)
 import os
-if os.environ.get('V3A_FUSED_QKV') == '0':
-    m.fused_qkv = False
+if os.environ.get('V3A_FUSED_QKV') == '1':
+    m.fused_qkv = True   # A/B: q | k | V^T from one launch (transposed-tail tile)
 if os.environ.get('V3A_CTX_VO') == '0':
     m.ctx_vo = False   # A/B: flash cross-attention + to_out GEMM instead of the cached-context form
 del sd

@@ -150,8 +150,9 @@ class WanDiT:
         # head_dim = 128, the (merged) key count is <= 128 and the block GEMMs run in bf16; False = flash attention + to_out GEMM.
         self.ctx_vo = True
         # q | k | V^T of a block's self-attention from ONE GEMM launch (transposed tail, csrc/gemm_bf16.hip tile 13) instead of a q | k and a V^T
-        # launch: bit-identical, 117.5 -> ~105 us per block at 1.3B (three full rounds instead of 2 + 1).  False = the two launches.
-        self.fused_qkv = True
+        # launch: bit-identical.  OFF by default: measured 114.8 against 119.1 us in isolation but 118.4 against 117.5 us inside the model and
+        # 27.03-27.20 against 27.02-27.11 ms on the step (every ROUND of a launch pays the per-tile fixed cost: DESIGN.md section 9, round 5 (d))
+        self.fused_qkv = False
         self._load(state_dict)
 
     def _sp_ksplit(self, M: int, N: int, K: int) -> int:
