@@ -14,6 +14,11 @@ import oracle_cache as OC
 from oracle import recon as R
 from oracle import wan_dit as O
 
+def _ov():
+    from oracle import wan_vae as OV
+    return OV
+
+
 RECON_MH = dict(C=128, heads=2, n_dino=22, depth=24, cam_heads=4, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
 DIT_DEPTHS = (1, 2, 4, 8, 16, 30)
 
@@ -137,6 +142,23 @@ def dit_config4_two_blocks() -> SimpleNamespace:
     return SimpleNamespace(name="dit_config4_14B_two_blocks_N4096_B2", fingerprint=fp, sources=(O,), case_fns=(dit_config4_two_blocks,), compute=compute, ocfg=ocfg, sd=sd, lat=lat, text=text, t=t)
 
 
+def vae_full() -> SimpleNamespace:
+    """Wan VAE decoder at production size (base_dim 96, latent [1,16,4,64,64] -> 13 x 512^2), contract oracle:
+    tests/test_fullsize_gpu.py::test_full_size_vae_decode_matches_oracle"""
+    from oracle import wan_vae as OV
+    cfg = OV.WanVAEConfig()
+    sd = OV.make_weights(cfg, seed=31)
+    z = torch.randn(1, 16, 4, 64, 64, generator=torch.Generator().manual_seed(32))
+
+    def compute():
+        t0 = time.time()
+        ref = OV.decode(sd, cfg, z, emulate_bf16=True)
+        return dict(ref=ref, clamped_fraction=(ref.abs() >= 1.0).float().mean().item(), seconds=time.time() - t0)
+
+    fp = OC.checksum(z, sd["decoder.conv_in.weight"], sd["decoder.conv_out.weight"])
+    return SimpleNamespace(name="vae_full_base96_13x512", fingerprint=fp, sources=(OV,), case_fns=(vae_full,), compute=compute, cfg=cfg, sd=sd, z=z)
+
+
 CONFIG4_DEPTHS = (1, 2, 4, 8)
 
 
@@ -165,9 +187,9 @@ def dit_config4_eight_blocks() -> SimpleNamespace:
                            ocfg=ocfg, sd=sd, lat=lat, text=text, t=t)
 
 
-CASES = {"dit_config4_eight_blocks": dit_config4_eight_blocks, "recon_full": recon_full, "recon_config3": recon_config3, "dit_full_depth": dit_full_depth, "dit_config4_two_blocks": dit_config4_two_blocks}
+CASES = {"vae_full": vae_full, "dit_config4_eight_blocks": dit_config4_eight_blocks, "recon_full": recon_full, "recon_config3": recon_config3, "dit_full_depth": dit_full_depth, "dit_config4_two_blocks": dit_config4_two_blocks}
 # digest name -> (oracle modules, case functions) whose source it depends on (what each case passes as `sources` / `case_fns`; lets a CPU
 # test check every committed digest against the current sources without building the cases' gigabytes of weights)
 SOURCES = {"recon_full_C1024_S13": ((R,), (recon_full_weights, recon_full)), "recon_config3_S21_width128": ((R,), (recon_config3,)),
            "dit_full_depth_30_blocks_N4096": ((O,), (dit_full_depth,)), "dit_config4_14B_two_blocks_N4096_B2": ((O,), (dit_config4_two_blocks,)),
-           "dit_config4_14B_eight_blocks": ((O,), (dit_config4_eight_blocks,))}
+           "dit_config4_14B_eight_blocks": ((O,), (dit_config4_eight_blocks,)), "vae_full_base96_13x512": ((_ov(),), (vae_full,))}
