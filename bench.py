@@ -4,6 +4,8 @@ production shapes (BASELINE.json configs[1]; no checkpoint is reachable offline)
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...        (started as a plain process it re-launches ITSELF under torch.distributed.run, 127.0.0.1 rendezvous,
+                                         a free port, one rank per GPU, and still prints the one JSON line - `spawn_ranks` below)
 
 One "step" = one complete scene.  N>1 = data parallel over prompts exactly like the reference (prompt_list[rank::world],
 /root/reference/inference_t23d.py:62): every rank owns whole scenes, no data-path collective (weak scaling).
@@ -184,6 +186,73 @@ def sustained_clock(load, device_index, samples=4):
             "note": "untimed extra; the MFMA roof at this clock is 2500 x sclk / 2400 TFLOP/s"}
 
 
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` started WITHOUT a launcher: run this very command line under torch.distributed.run (one rank per GPU of
+    this node, rendezvous on 127.0.0.1 - the container hostname may not resolve - on a port the kernel just handed out), pass the children's
+    stdout / stderr through, return their exit code.  Rank 0 of the children prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL / tensor sharing across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def timed_steps(step, steps: int, warmup: int, sync, world: int, reduce_max):
+    """The measurement contract shared by the real run and the launch self-test: `warmup` untimed steps, then EXACTLY `steps` steps between
+    two (barrier + device synchronise) brackets; the time reported is the MAXIMUM over ranks."""
+    for i in range(warmup):
+        step(-1 - i, False)
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        out = step(i, i == steps - 1)
+    sync()
+    dt = time.perf_counter() - t0
+    return (reduce_max(dt) if world > 1 else dt), dt, out
+
+
+def launch_self_test(a, world: int, rank: int) -> None:
+    """--launch-self-test: the rendezvous / barrier / max-over-ranks / one-line skeleton of this file on the CPU (gloo) around a stub step
+    that only sleeps - what tests/test_host_logic.py runs with --gpus 2 to prove that a launcher-less `python bench.py --gpus N` comes
+    up as N ranks and prints ONE line.  Not a measurement: the line says so."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+
+    def reduce_max(dt):
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
+    seen = []
+    dt, _, _ = timed_steps(lambda i, last: (time.sleep(0.01 * (1 + rank)), seen.append(i))[1], a.steps, a.warmup, sync, world, reduce_max)
+    counts = [None] * world
+    if world > 1:
+        dist.all_gather_object(counts, len(seen))
+    else:
+        counts = [len(seen)]
+    if rank == 0:
+        print(json.dumps({"metric": "launch self-test (stub step, no model, no GPU)", "value": world * a.steps / dt, "unit": "stub steps/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none (launch self-test)",
+                          "config": {"workload": "stub", "steps_run_per_rank_incl_warmup": counts,
+                                     "rccl": {"backend": dist.get_backend() if world > 1 else "none", "world_size": world,
+                                              "launched_by": os.environ.get("V3A_BENCH_LAUNCHED_BY", "external launcher")}}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,13 +273,20 @@ def main():
     ap.add_argument("--parallel", choices=["dp", "scene"], default="dp",
                     help="dp: one prompt per GPU, no data-path collective (the reference's split; the headline metric). "
                          "scene: all ranks cooperate on ONE scene (CFG-parallel x sequence-parallel DiT over RCCL; latency mode)")
+    ap.add_argument("--launch-self-test", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N` (the way the driver calls --gpus 1): become the launcher of our own N ranks
+        os.environ["V3A_BENCH_LAUNCHED_BY"] = "bench.py itself (no launcher in the environment)"
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} must be launched with torch.distributed.run --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: use --nproc-per-node {a.gpus}")
+    if a.launch_self_test:
+        return launch_self_test(a, world, rank)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     if world > 1:
@@ -240,12 +316,12 @@ def main():
     Tl = (a.num_frames - 1) // 4 + 1
     N = Tl * 32 * 32
 
-    def scene(i, timings=None):
+    def scene(i, timings=None, stage_flops=None):
         # the reference seeds once per process and strides prompts over ranks: scene i of this rank = global prompt i*world+rank
         g = torch.Generator().manual_seed(12413 + (i if coop else i * world + rank))
         lat0 = torch.randn(1, 16, Tl, 64, 64, generator=g)
         out, _, _ = model.generate(pe, ne, latents=lat0, num_frames=a.num_frames, num_inference_steps=a.denoise_steps,
-                                   guidance_scale=7.5, timings=timings)
+                                   guidance_scale=7.5, timings=timings, stage_flops=stage_flops)
         return out
 
     def sync():
@@ -254,34 +330,35 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        scene(-1 - i)
     # dominant kernel = the bf16 GEMM tile every N=1536/3072/8960-wide projection resolves to (one kernel symbol)
     f8 = a.dtype == "fp8"   # then the dominant kernel is the e4m3 form of the same tile
     dom_tile = lib.load().v3a_gemm_fp8_pick_tile(2 * N, cfg.dim) if f8 else lib.load().v3a_gemm_pick_tile(2 * N, cfg.dim)
-    # every 7th launch of the symbol is bracketed by events (7 is coprime to the 5 launches of the symbol per DiT block, so every shape is
-    # sampled equally): ~1300 samples per scene, and the event pairs no longer cost the probed scene 3 % of its time
+    # every 7th launch of the symbol is bracketed by events.  Per DiT block the symbol runs FIVE times - self-attention out-projection,
+    # cross-attention to_q, the batched cached-context GEMM (two per-prompt operands in one launch), FFN2 and the two-round q|k
+    # projection - and 7 is coprime to 5, so every shape is sampled equally: 30 blocks x 5 x 100 forwards / 7 = ~2140 samples per scene,
+    # and the event pairs do not cost the probed scene 3 % of its time as bracketing every launch did
     probe = ops.GemmProbe(dom_tile, fp8=f8, stride=7)
     ops.set_gemm_probe(probe)
     stage = SceneTimes()
-    sync()
-    t0 = time.perf_counter()
-    out = None
-    for i in range(a.steps):
-        last = i == a.steps - 1
-        probe.active = last  # HIP-event pairs around every launch of the dominant kernel during the last timed scene
-        out = scene(i, stage if last else None)
-    sync()
-    dt = time.perf_counter() - t0
+
+    def step(i, last):
+        probe.active = last and i >= 0   # HIP-event pairs around the sampled launches of the dominant kernel during the last timed scene
+        return scene(i, stage if (last and i >= 0) else None)
+
+    def reduce_max(t):
+        tt = torch.tensor([t], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return tt.item()
+
+    dt_max, dt, out = timed_steps(step, a.steps, a.warmup, sync, world, reduce_max)
     probe.active = False
     ops.set_gemm_probe(None)
     per_rank = rccl_info = None
     if world > 1:
         # what torch.distributed actually ran on: a SCALE run shows the rank count / backend it saw without a code change
         rccl_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gpus_visible_to_rank0": torch.cuda.device_count(),
-                     "mode": "scene (CFG x sequence parallel, RCCL all-gathers on the data path)" if coop else "dp (no data-path collective)"}
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                     "mode": "scene (CFG x sequence parallel, RCCL all-gathers on the data path)" if coop else "dp (no data-path collective)",
+                     "launched_by": os.environ.get("V3A_BENCH_LAUNCHED_BY", "external launcher (torch.distributed.run)")}
         # every rank's wall time and stage times of its last scene (not part of the timed region): shows WHICH stage or rank is slow
         mine = torch.tensor([dt, stage.denoise_ms, stage.vae_ms, stage.recon_ms], device=dev, dtype=torch.float64)
         allr = torch.empty(world, 4, device=dev, dtype=torch.float64)
@@ -297,7 +374,7 @@ def main():
             for pr, v in zip(per_rank, allr.cpu().tolist()):
                 pr["recon_view_shard"] = {"views": int(v[0]), "backbone_ms": round(v[1], 1), "camera_replicated_ms": round(v[2], 1),
                                           "heads_ms": round(v[3], 1), "gather_and_tail_ms": round(v[4], 1)}
-        dt = tt.item()
+    dt = dt_max
     comm = None
     if coop:
         # RCCL time of the sequence-parallel all-gathers on their own: two extra denoise steps, untimed, with every all-gather run
@@ -388,6 +465,12 @@ def main():
         # what the boxes differ in: the shader clock the firmware sustains under THIS load (the roofline's 2.5 PFLOP/s is quoted at 2.4 GHz).
         # rocm-smi is sampled from a thread while untimed extra scenes run; any failure leaves the field null.
         box["clock_under_load"] = None if coop else sustained_clock(lambda: scene(a.steps), local)
+    # algorithmic FLOPs of every matrix-pipe launch of one scene, stage by stage (an untimed extra scene with ops.FlopMeter installed; the
+    # denoise loop is eager unless V3A_GRAPH=1, so its launches are counted too): the stage-level roofline fractions beside the kernel-level one
+    stage_flops = {}
+    if rank == 0 and not coop:
+        scene(a.steps + 1, None, stage_flops)
+        torch.cuda.synchronize()
     if rank == 0:
         ps = probe.summary()
         ach = ps["flops_per_launch"] / (ps["avg_ms"] * 1e-3) / 1e12 if ps["launches"] else 0.0
@@ -444,6 +527,26 @@ def main():
                          "launches_timed": ps["launches"], "launch_sampling": "every 7th launch of the symbol in the last timed scene", "avg_launch_ms": round(ps["avg_ms"], 4),
                          "flops_per_launch": ps["flops_per_launch"]},
         }
+        pk_tf = FP8_MFMA_PEAK_TFLOPS if f8 else BF16_MFMA_PEAK_TFLOPS
+
+        def srow(flops, ms, note, kinds=None):
+            tf = flops / (ms * 1e-3) / 1e12 if ms else 0.0
+            r = {"flops": flops, "ms": round(ms, 2), "achieved_tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / pk_tf, 4), "what": note}
+            if kinds:
+                r["flops_by_kind"] = {k: round(v, 0) for k, v in sorted(kinds.items())}
+            return r
+        line["stage_roofline"] = {
+            "peak_tflops": pk_tf,
+            "dit_model": srow(2 * a.denoise_steps * fwd_flops, stage.denoise_ms, "BASELINE.md section 2 formula x 2 CFG branches x denoise steps / the denoise stage's time"),
+            "dit_executed": srow(2 * a.denoise_steps * dit_flops_executed(N, cfg.dim, cfg.ffn_dim, cfg.num_layers, ctx_keys, hxk), stage.denoise_ms,
+                                 "the FLOPs the product executes (merged padding keys, per-prompt context cache, cached-context cross-attention)"),
+        }
+        names = {"denoise": ("dit_metered", stage.denoise_ms), "vae": ("vae", stage.vae_ms), "recon": ("recon", stage.recon_ms)}
+        for st_name, kinds in stage_flops.items():
+            key, ms = names[st_name]
+            line["stage_roofline"][key] = srow(sum(kinds.values()), ms, "sum of the algorithmic FLOPs of every GEMM / convolution / attention launch of the stage "
+                                               "(ops.FlopMeter, one untimed extra scene; fp32-equivalent convolutions counted once, not as their three bf16 products) "
+                                               "/ the stage's time in the last timed scene", kinds)
         clk = (box or {}).get("clock_under_load")
         if clk:   # the same achieved rate against the roof at the clock the box actually held (information beside `frac`, which stays on the guide's peak)
             pk = (FP8_MFMA_PEAK_TFLOPS if f8 else BF16_MFMA_PEAK_TFLOPS) * clk["sclk_mhz"] / 2400.0

@@ -23,7 +23,7 @@ extern "C" {
 #define V3A_ERR_LAUNCH (-3)
 #define V3A_ERR_WORKSPACE (-4)
 
-int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 20) */
+int v3a_abi_version(void);            /* bumps whenever a signature changes (currently 21) */
 const char* v3a_build_info(void);     /* "gfx950 <date> <compiler>" */
 
 /* ------------------------------------------------------------------------------------------------
@@ -97,6 +97,9 @@ size_t v3a_gemm_split_workspace_bytes(int M, int N, int split_k);
 int v3a_gemm_num_tiles(void);
 int v3a_gemm_pick_tile(int M, int N);   /* the tile index tile=-1 resolves to (profiling / roofline bookkeeping) */
 int v3a_gemm_pick_tile_act(int M, int N, int act);   /* ... for a launch with activation `act` (ties between mirrored tiles depend on it) */
+/* ... the tile a launch REALLY runs on: `mult` = batch / split_k problems side by side, `has_tail` != 0 when C_t is set (the
+ * transposed-tail tile whatever M, N).  An explicit `tile` >= 0 that contradicts C_t is rejected with V3A_ERR_ARG by the launch. */
+int v3a_gemm_pick_tile_ex(int M, int N, int act, int mult, int has_tail);
 const char* v3a_gemm_tile_name(int tile);
 
 /* e4m3 (OCP fp8) form of v3a_gemm_bf16_nt for BASELINE config #4 (Wan-14B: "MFMA bf16/fp8 GEMMs for the attention/FFN contractions"):

@@ -305,6 +305,9 @@ def recon_tiny_conf():
                               "means": gs.means, "opacities": gs.opacities, "scales": gs.scales})
 
 
+DENOISE_LOOP_BLOCK_SHA256 = "097e7953bc87ac4d7da05ef37ee830a6a838ba17f9436763f3e9ec6890727a62"   # dedented train_vdm.py:586-624 as reviewed
+
+
 def denoise_loop_ref():
     """SURVEY row A0.  The pipeline class the reference calls (diffusers WanPipeline) is not in the image, but the reference holds ONE in-tree
     spelling of the same CFG denoise loop: /root/reference/train_vdm.py:586-624 (B = 2 batching [cond | uncond], `pred.chunk(2)` order,
@@ -325,6 +328,13 @@ def denoise_loop_ref():
     end = next(i for i, l in enumerate(lines) if "latents = latents / latents_std + latents_mean" in l)
     assert 580 < start < end < 640, (start, end)        # train_vdm.py:586-624
     block = textwrap.dedent("\n".join(lines[start:end + 1]))
+    # /root/reference is untrusted content and these lines are about to be EXECUTED with the developer's privileges: they must be exactly
+    # the 39 lines that were read and reviewed when the fixture was written, not "whatever sits between the two marker lines today".
+    import hashlib
+    got = hashlib.sha256(block.encode()).hexdigest()
+    if got != DENOISE_LOOP_BLOCK_SHA256:
+        raise SystemExit(f"train_vdm.py:{start + 1}-{end + 1} changed (sha256 {got}, reviewed {DENOISE_LOOP_BLOCK_SHA256}): refusing to exec it.\n"
+                         "Review the new text, then update DENOISE_LOOP_BLOCK_SHA256:\n" + block)
     sig = inspect.signature(W.AutoencoderKLWan.__init__).parameters
     mean, std = sig["latents_mean"].default, sig["latents_std"].default
     steps, shift, guidance, text_dim = 10, 5.0, 5.25, 32

@@ -480,3 +480,29 @@ def test_shard_views_layout():
             sizes = [b - a for a, b in v]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
     assert E.shard_views(13, 4) == [(0, 4), (4, 7), (7, 10), (10, 13)] and E.shard_views(21, 8)[0] == (0, 3)
+
+
+def test_bench_started_without_a_launcher_spawns_its_own_ranks_gloo():
+    """`python bench.py --gpus 2` the way the driver calls `--gpus 1` (no torch.distributed.run around it): bench.py must become the launcher of
+    its own two ranks (127.0.0.1 rendezvous on a free port), run the barrier / max-over-ranks skeleton and print exactly ONE JSON line that
+    says how many ranks it really ran on.  `--launch-self-test` swaps the scene for a stub step on gloo / CPU; everything around it is the
+    code path of the real multi-GPU run (spawn_ranks, timed_steps)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--launch-self-test"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["config"]["rccl"]["world_size"] == 2 and "bench.py itself" in line["config"]["rccl"]["launched_by"]
+    assert line["config"]["steps_run_per_rank_incl_warmup"] == [4, 4]          # W untimed + EXACTLY K timed steps on every rank
+    # the stub step sleeps 10 ms x (rank + 1): the reported time is the MAX over ranks (>= 3 x 20 ms), not rank 0's own 30 ms
+    assert line["ms_per_step"] >= 19.0, line
+
+
+def test_bench_rejects_a_launcher_with_the_wrong_rank_count():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--launch-self-test"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)

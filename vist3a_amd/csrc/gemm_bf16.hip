@@ -739,8 +739,10 @@ int pick_tile(int M, int N, bool conv = false, int mult = 1, int act = 0) {
 }
 
 int launch(const GemmP& p, int ti, int conv, void* stream, int nz = 1) {   // conv: 0 GEMM, 1 convolution, 2 split-bf16 convolution
-  if (p.Ct) ti = kTileTT;
-  else if (ti < 0 || ti >= kNumTiles) {
+  if (p.Ct) {
+    if (ti >= 0 && ti != kTileTT) return V3A_ERR_ARG;   // an explicit tile must be the one that runs: the transposed tail exists on tile 13 only
+    ti = kTileTT;
+  } else if (ti < 0 || ti >= kNumTiles) {
     ti = pick_tile(p.M, p.N, conv != 0, nz, p.act);
     // split-bf16 convolutions walk a 3x longer K: a layer that cannot give every CU a big tile (the 16^2 / 32^2 levels of the DPT pyramid:
     // < 128 tiles of 256 x 256) is latency-bound per tile and wants MANY small co-resident tiles (tools/conv_split_sweep.py, 13 views:
@@ -867,6 +869,12 @@ constexpr int kKnownFlags = V3A_GEMM_BIAS_ROW | V3A_GEMM_SCALE_PER_BATCH | V3A_G
 extern "C" int v3a_gemm_num_tiles(void) { return kNumTiles; }
 extern "C" int v3a_gemm_pick_tile(int M, int N) { return (M > 0 && N > 0) ? pick_tile(M, N) : V3A_ERR_SHAPE; }
 extern "C" int v3a_gemm_pick_tile_act(int M, int N, int act) { return (M > 0 && N > 0) ? pick_tile(M, N, false, 1, act) : V3A_ERR_SHAPE; }
+// the tile a launch with these properties REALLY runs on (what `tile = -1` resolves to in v3a_gemm_bf16_nt): `mult` = batch count or
+// split-K slices side by side on blockIdx.y, `has_tail` = v3a_gemm_args.C_t set (always the transposed-tail tile)
+extern "C" int v3a_gemm_pick_tile_ex(int M, int N, int act, int mult, int has_tail) {
+  if (M <= 0 || N <= 0 || mult <= 0) return V3A_ERR_SHAPE;
+  return has_tail ? kTileTT : pick_tile(M, N, false, mult, act);
+}
 extern "C" const char* v3a_gemm_tile_name(int t) { return (t >= 0 && t < kNumTiles) ? kTiles[t].name : ""; }
 
 extern "C" int v3a_gemm_bf16_nt(const v3a_gemm_args* a, void* stream) {

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void segments_kernel(const SegP p) {
 constexpr int CH = 64;      // sorted points per fusion chunk
 
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {   // exact and order-independent: the result is deterministic
-  if (v >= 0.f) atomicMax((int*)addr, __float_as_int(v));
+  // branch on the SIGN BIT, not on v >= 0: -0.0f (0x80000000 = INT_MIN as a signed int) would never replace the -inf initial value
+  if (__float_as_int(v) >= 0) atomicMax((int*)addr, __float_as_int(v));
   else atomicMin((unsigned int*)addr, __float_as_uint(v));
 }
 

@@ -207,6 +207,7 @@ SYMBOLS = {
     "v3a_attention_fwd_fp8": (C.c_int, [C.POINTER(AttnFp8Args), C.c_void_p]),
     "v3a_gemm_split_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "v3a_gemm_pick_tile_act": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "v3a_gemm_pick_tile_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "v3a_gemm_fp8_nt": (C.c_int, [C.POINTER(GemmFp8Args), C.c_void_p]),
     "v3a_gemm_fp8_num_tiles": (C.c_int, []),
     "v3a_gemm_fp8_pick_tile": (C.c_int, [C.c_int, C.c_int]),
@@ -238,7 +239,7 @@ SYMBOLS = {
 }
 
 _lib = None
-EXPECTED_ABI = 20   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
+EXPECTED_ABI = 21   # = v3a_abi_version() of csrc/capi.hip; bumped together with every struct / signature change in include/vist3a_hip.h
 
 
 class HipLibraryError(RuntimeError):

@@ -110,7 +110,9 @@ class StitchVAE3D(torch.nn.Module):
         # context_image = (context_image + 1) / 2 in fp32 (anysplat_stitched.py:174-175), whatever dtype the image arrived in
         img01 = (image_cl.float() + 1) / 2
         img01[..., 3:] = 0
-        x, g = eng.token_workspace(S, H, W)
+        sharded = grp is not None and grp.world > 1
+        # (the view-sharded path lays the scene's tokens out in a private buffer and never touches the S-view workspace: constants only)
+        x, g = (None, eng.geometry_constants(S, H, W)) if sharded else eng.token_workspace(S, H, W)
         hw, Pp, nsp = g["hw"], g["Pp"], g["nsp"]
         cw = self._conv_weight()
         oshape = [(lat_cl.shape[i] + 2 * st.padding3[i] - st.kernel3[i]) // st.stride3[i] + 1 for i in range(3)]

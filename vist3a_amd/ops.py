@@ -63,6 +63,31 @@ def set_gemm_probe(p: Optional[GemmProbe]) -> None:
     _probe = p
 
 
+class FlopMeter:
+    """Algorithmic FLOPs of the matrix-pipe launches issued through this module while the meter is installed (`set_flop_meter`), by kind:
+    GEMM 2MNK, convolution 2 x output pixels x Cout x taps x Cin (REAL channels; the fp32-equivalent form counts the fp32 convolution once,
+    not its three bf16 products), attention 4 B H Nq Nk D over the keys that take part.  bench.py divides a stage's total by the stage's
+    time for `stage_roofline`.  Launches replayed from a hipGraph do not pass through Python and are not counted."""
+
+    def __init__(self):
+        self.by_kind = {}
+
+    def add(self, kind: str, flops: float) -> None:
+        self.by_kind[kind] = self.by_kind.get(kind, 0.0) + float(flops)
+
+    @property
+    def total(self) -> float:
+        return sum(self.by_kind.values())
+
+
+_meter: Optional[FlopMeter] = None
+
+
+def set_flop_meter(m: Optional[FlopMeter]) -> None:
+    global _meter
+    _meter = m
+
+
 _gemm_ws = {}   # per (device, thread) split-K partial buffer (see _attn_ws)
 
 
@@ -188,6 +213,8 @@ def gemm(
         if ws is None or ws.numel() < nbytes:
             ws = _gemm_ws[wk] = torch.empty(nbytes, device=a.device, dtype=torch.uint8)
         args.split_k, args.workspace = split_k, ws.data_ptr()
+    if _meter is not None:
+        _meter.add("gemm_fp8" if a_scale is not None else "gemm", 2.0 * M * N * K * nb)
     if a_scale is not None:
         for t, n, nm in ((a_scale, M, "a_scale"), (w_scale, N, "w_scale")):
             if t is None or t.dtype != f32 or not t.is_contiguous() or t.numel() != n:
@@ -205,7 +232,8 @@ def gemm(
             pr.flops += 2.0 * M * N * K
         return out
     pr = _probe
-    if t_out is None and pr is not None and pr.active and not pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile_act(M, N, act)) == pr.tile and pr.take():
+    # the tile the C side really runs (batch / split-K slices count towards the tile choice; a transposed tail forces its own tile)
+    if pr is not None and pr.active and not pr.fp8 and (tile if tile >= 0 else L.load().v3a_gemm_pick_tile_ex(M, N, act, max(nb, split_k), int(t_out is not None))) == pr.tile and pr.take():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         L.check(L.load().v3a_gemm_bf16_nt(C.byref(args), _stream()), "v3a_gemm_bf16_nt")
@@ -248,6 +276,8 @@ def _gemm_skinny(x, wbig, bias, out, act, residual, out_f32, transposed):
         flags |= L.GEMM_OUT_F32
     args = L.GemmSkinnyArgs(_ptr(x), _ptr(wbig), _ptr(out), _ptr(bias), _ptr(residual), Ms, Nb, K, x.stride(0), wbig.stride(0),
                             out.stride(0), ldr, act, flags, int(transposed), _ptr(ws), ws.numel())
+    if _meter is not None:
+        _meter.add("gemm_skinny", 2.0 * Ms * Nb * K)
     L.check(lib.v3a_gemm_skinny_bf16(C.byref(args), _stream()), "v3a_gemm_skinny_bf16")
     return out
 
@@ -354,6 +384,8 @@ def conv(
     )
     if form_scale is not None and tile == -1 and cw.w_halo is not None:
         args.tile = -2 if L.load().v3a_conv_halo_tiles(C.byref(args)) * form_scale >= 512 else -3
+    if _meter is not None:
+        _meter.add("conv", 2.0 * M * cw.Cout * kT * kH * kW * cw.Cin)
     L.check(L.load().v3a_conv_bf16(C.byref(args), _stream()), "v3a_conv_bf16")
     return out
 
@@ -532,6 +564,8 @@ def conv_split(
     if form_frames is not None and tile == -1 and cw.w_halo is not None:
         per_frame = L.load().v3a_conv_split_halo_tiles(C.byref(args)) // T          # 0: the layer has no halo form
         args.c.tile = -2 if per_frame * form_frames >= 128 else -3
+    if _meter is not None:
+        _meter.add("conv_f32_equivalent", 2.0 * oT * oH * oW * cw.Cout * kT * kH * kW * cw.Cin)
     L.check(L.load().v3a_conv_split(C.byref(args), _stream()), "v3a_conv_split")
     return out
 
@@ -578,6 +612,8 @@ def attention(
         _ptr(key_bias), key_bias.stride(0) if key_bias is not None else 0, key_bias_first,
         kv_seg, k_seg_stride, vt_seg_stride, kv_split, _ptr(ws),
     )
+    if _meter is not None:
+        _meter.add("attention", 4.0 * B * H * Nq * (Nk * kv_valid / kv_period if kv_period > 0 else Nk) * D)
     L.check(L.load().v3a_attention_fwd_bf16(C.byref(args), _stream()), "v3a_attention_fwd_bf16")
     return out
 
@@ -605,6 +641,8 @@ def xattn_probs(
         key_bias.stride(0) if key_bias is not None else 0, key_bias_first, float(scale if scale is not None else 128 ** -0.5),
         _ptr(q_row_sumsq), q_row_sumsq.shape[1] if q_row_sumsq is not None else 0, float(q_eps),
     )
+    if _meter is not None:
+        _meter.add("attention", 2.0 * B * H * Nq * Nk * 128)   # scores only: P.V is the finishing GEMM's
     L.check(L.load().v3a_xattn_probs_bf16(C.byref(args), _stream()), "v3a_xattn_probs_bf16")
     return out
 
@@ -653,6 +691,8 @@ def attention_fp8(q8: torch.Tensor, k8: torch.Tensor, vt8: torch.Tensor, out: to
                          q8.stride(0), k8.stride(0), vt8.stride(0), out.stride(0), B, H, Nq, Nk, 128,
                          float(scale if scale is not None else 128 ** -0.5), float(q_scale), float(k_scale), float(v_scale),
                          kv_seg, k_seg_stride, vt_seg_stride, kv_split, _ptr(ws))
+    if _meter is not None:
+        _meter.add("attention_fp8", 4.0 * B * H * Nq * Nk * 128)
     L.check(L.load().v3a_attention_fwd_fp8(C.byref(args), _stream()), "v3a_attention_fwd_fp8")
     return out
 
@@ -861,6 +901,8 @@ def linear_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, device=x.device, dtype=f32)
+    if _meter is not None:
+        _meter.add("linear_f32", 2.0 * M * N * K)
     L.check(L.load().v3a_linear_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(residual), _ptr(gamma), M, N, K, x.stride(0), N,
                                     residual.stride(0) if residual is not None else 0, act, _stream()), "v3a_linear_f32")
     return y

@@ -198,9 +198,11 @@ class ReconEngine:
         self._geo: Dict[tuple, dict] = {}
 
     # ------------------------------------------------------------------ per-resolution constants / workspaces
-    def _geometry(self, S, H, W, tag=None):
-        """workspaces + per-resolution constants for S views; `tag` separates the workspaces of virtual ranks (threads) sharing this engine"""
-        key = (S, H, W) if tag is None else (S, H, W, tag)
+    def geometry_constants(self, S, H, W):
+        """per-resolution CONSTANTS for S views (token grid, positional embedding of the patch tokens, special-token rows, rotary table): no
+        workspace.  What a caller needs that only lays tokens out (the view-sharded path's full-scene token buffer) - `_geometry` adds the
+        S-view workspaces (0.7-1 GB at 13 views, width 1024) on top of these."""
+        key = ("const", S, H, W)
         g = self._geo.get(key)
         if g is not None:
             return g
@@ -220,7 +222,18 @@ class ReconEngine:
         cam1 = torch.cat([self.camera_token[0, 1], self.register_token[0, 1]], 0)
         sp = torch.stack([cam0] + [cam1] * (S - 1), 0)  # [S, nsp, C]
         g["special_agg"] = sp.to(bf16).float().to(dev)
-        M = S * Pp
+        self._geo[key] = g
+        return g
+
+    def _geometry(self, S, H, W, tag=None):
+        """workspaces + per-resolution constants for S views; `tag` separates the workspaces of virtual ranks (threads) sharing this engine"""
+        key = (S, H, W) if tag is None else (S, H, W, tag)
+        g = self._geo.get(key)
+        if g is not None:
+            return g
+        cfg, dev = self.cfg, self.dev
+        g = dict(self.geometry_constants(S, H, W))      # (the constant tensors are shared, the dict is this workspace's own)
+        M, C = g["M"], cfg.C
         z = lambda *s, dt=bf16: torch.zeros(*s, device=dev, dtype=dt)
         g.update(x=z(M, C), xf=z(M, C, dt=f32), n=z(M, C), qk=z(M, 2 * C), vt=z(C, M + 64), ao=z(M, C), h=z(M, 4 * C),
                  taps=[z(M, 2 * C, dt=f32) for _ in cfg.taps])
@@ -324,39 +337,50 @@ class ReconEngine:
         return outs
 
     # ------------------------------------------------------------------ DPT trunk (channels-last bf16)
+    @staticmethod
+    def _conv_bf16(g, S):
+        """ops.conv with the kernel-FORM hint of a view-sharded forward: a rank that holds S of the scene's g["form_frames"] views chooses
+        halo-tile vs implicit GEMM as the whole scene would (the two forms differ in fp32 summation order), like `form_frames` does on the
+        fp32-equivalent path.  (At the production DPT widths no bf16 layer has a halo form - 256 channels are not a multiple of 96 - so
+        this only matters for other head widths.)"""
+        ff = g.get("form_frames")
+        fs = (ff / S) if (ff and S) else None
+        return lambda x_, cw_, **kw: ops.conv(x_, cw_, form_scale=fs, **kw)
+
     def _dpt_trunk(self, g, hd: _DPT, S, H, W):
         cfg, dev = self.cfg, self.dev
         hp, wp, hw, Pp, nsp = g["hp"], g["wp"], g["hw"], g["Pp"], g["nsp"]
         C2 = 2 * cfg.C
         lv = []
+        cv = self._conv_bf16(g, S)
         for i, tap in enumerate(g["taps"]):
             n = ops.layernorm(tap, weight=hd.nw, bias=hd.nb, eps=1e-5, M=S * hw, in_rows=(hw, Pp - hw, nsp)).view(S, hp, wp, C2)
-            x = ops.conv(n, hd.proj[i], residual=hd.pos(hd.proj[i].CoutP, hp, wp, W, H, dev), res_row_mod=hw)
+            x = cv(n, hd.proj[i], residual=hd.pos(hd.proj[i].CoutP, hp, wp, W, H, dev), res_row_mod=hw)
             if i < 2:
                 per_dy, k, co = hd.up[i]
                 up = torch.empty(S, hp * k, wp, k * co, device=dev, dtype=bf16)   # = [S, hp*k, wp*k, co]
                 for dy, cwt in enumerate(per_dy):   # pixel m = (s, y, x) -> row ((s*hp + y)*k + dy)*wp + x of the [.., k*co] matrix
-                    ops.conv(x, cwt, out=up, out_rows=(wp, (k - 1) * wp, dy * wp))
+                    cv(x, cwt, out=up, out_rows=(wp, (k - 1) * wp, dy * wp))
                 x = up.view(S, hp * k, wp * k, co)
             elif i == 3:
-                x = ops.conv(x, hd.down, stride=(1, 2, 2), pad=(0, 1, 1))
-            lv.append(ops.conv(x, hd.rn[i], pad=(0, 1, 1), relu_out=True))  # ReLU: only ever consumed through relu()
+                x = cv(x, hd.down, stride=(1, 2, 2), pad=(0, 1, 1))
+            lv.append(cv(x, hd.rn[i], pad=(0, 1, 1), relu_out=True))  # ReLU: only ever consumed through relu()
         R = L.ACT_RELU
 
         def rcu2_out(f, s, size):
-            c1 = ops.conv(s, f["c21"], pad=(0, 1, 1), act=R)
-            o = ops.conv(c1, f["c22"], pad=(0, 1, 1), residual=s)
-            o = ops.conv(o, f["out"])  # 1x1 out_conv commutes with the bilinear resize that follows it in the reference
+            c1 = cv(s, f["c21"], pad=(0, 1, 1), act=R)
+            o = cv(c1, f["c22"], pad=(0, 1, 1), residual=s)
+            o = cv(o, f["out"])  # 1x1 out_conv commutes with the bilinear resize that follows it in the reference
             return ops.bilinear_cl(o, size, align_corners=True)
 
         o = rcu2_out(hd.fus[4], lv[3], lv[2].shape[1:3])
         for r, l in ((3, lv[2]), (2, lv[1]), (1, lv[0])):
             f = hd.fus[r]
-            c1 = ops.conv(l, f["c11"], pad=(0, 1, 1), act=R)
-            s = ops.conv(c1, f["c12"], pad=(0, 1, 1), residual=l, residual2=o, relu_out=True)  # relu(x0 + RCU1(x1))
+            c1 = cv(l, f["c11"], pad=(0, 1, 1), act=R)
+            s = cv(c1, f["c12"], pad=(0, 1, 1), residual=l, residual2=o, relu_out=True)  # relu(x0 + RCU1(x1))
             size = lv[r - 2].shape[1:3] if r > 1 else (l.shape[1] * 2, l.shape[2] * 2)
             o = rcu2_out(f, s, size)
-        return ops.conv(o, hd.oc1, pad=(0, 1, 1))
+        return cv(o, hd.oc1, pad=(0, 1, 1))
 
     # ------------------------------------------------------------------ DPT trunk, fp32-equivalent (pairs of bf16 planes)
     def _dpt_trunk_f32(self, g, hd: _DPT, S, H, W):
@@ -432,20 +456,21 @@ class ReconEngine:
             return (*self._heads_f32(g, S, H, W, img_cl.float().contiguous(), cam), ext, K)
         img_cl = img_cl.to(bf16)
         R = L.ACT_RELU
+        cv = self._conv_bf16(g, S)
         # depth head
         d = self.depth_head
         o = self._dpt_trunk(g, d, S, H, W)
         up = ops.bilinear_cl(o, (H, W), align_corners=True, table=d.pos(o.shape[-1], H, W, W, H, dev))
-        c = ops.conv(up, d.oc20, pad=(0, 1, 1), act=R)
-        raw = ops.conv(c, d.oc22, out_f32=True).view(S * H * W, -1)
+        c = cv(up, d.oc20, pad=(0, 1, 1), act=R)
+        raw = cv(c, d.oc22, out_f32=True).view(S * H * W, -1)
         depth, dconf, pts = ops.depth_unproject(raw, cam, S, H, W)
         # gaussian-parameter head
         q = self.gs_head
         o = self._dpt_trunk(g, q, S, H, W)
-        di = ops.conv(img_cl, q.merger, pad=(0, 3, 3), act=R)
+        di = cv(img_cl, q.merger, pad=(0, 3, 3), act=R)
         up = ops.bilinear_cl(o, (H, W), align_corners=True, add=di, table=q.pos(o.shape[-1], H, W, W, H, dev))
-        c = ops.conv(up, q.oc20, pad=(0, 1, 1), act=R)
-        raw_gs = ops.conv(c, q.oc22, out_f32=True).view(S * H * W, -1)
+        c = cv(up, q.oc20, pad=(0, 1, 1), act=R)
+        raw_gs = cv(c, q.oc22, out_f32=True).view(S * H * W, -1)
         return depth, dconf, pts, raw_gs, ext, K
 
     # ------------------------------------------------------------------ full forward
@@ -591,7 +616,7 @@ class ReconEngine:
 
     def token_buffer(self, S: int, H: int, W: int, tag) -> torch.Tensor:
         """a private [S * Pp, C] bf16 token buffer in the workspace layout (view-sharded forward: one per rank / virtual rank)"""
-        g = self._geometry(S, H, W)
+        g = self.geometry_constants(S, H, W)
         key = ("tokbuf", S, H, W, tag)
         t = self._geo.get(key)
         if t is None:

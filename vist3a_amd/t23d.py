@@ -49,6 +49,11 @@ class Text23DGS:
         step_fn = GraphedWanDiT(transformer) if graph else transformer
         self.pipe = WanT2VPipeline(step_fn, UniPCMultistepScheduler(flow_shift=flow_shift), vae=vae, device=device)
         self.ff_res = feedforward_resolution
+        # Scene-parallel runs (a DenoisePlan over > 1 ranks) also shard the VAE decode (H-strips) and the reconstruction (views) - bit-identical
+        # to the unsharded stages over 2 / 4 / 8 VIRTUAL ranks and in a 2-process gloo exchange test, but not yet run on real multi-GPU
+        # hardware (no such box in the build loop).  V3A_SCENE_SHARD_STAGES=0 (or shard_stages = False) keeps the 8 % of a scene these two
+        # stages are replicated on every rank, as a fallback switch for the first real multi-GPU run.
+        self.shard_stages = os.environ.get("V3A_SCENE_SHARD_STAGES", "1") != "0"
 
     @classmethod
     def synthetic(cls, dit_cfg: WanDiTConfig = WAN_1_3B, seed: int = 0, device="cuda", flow_shift: float = 5.0,
@@ -70,24 +75,44 @@ class Text23DGS:
     @torch.no_grad()
     def generate(self, prompt_embeds: torch.Tensor, negative_prompt_embeds: torch.Tensor, *, latents: Optional[torch.Tensor] = None,
                  generator: Optional[torch.Generator] = None, num_frames: int = 13, num_inference_steps: int = 50,
-                 guidance_scale: float = 7.5, height: int = 512, width: int = 512, timings: Optional[SceneTimes] = None):
-        """-> (EncoderOutput, de-normalised latents, channels-last decoded clip [T,512,512,8] in [-1,1])"""
+                 guidance_scale: float = 7.5, height: int = 512, width: int = 512, timings: Optional[SceneTimes] = None,
+                 stage_flops: Optional[dict] = None):
+        """-> (EncoderOutput, de-normalised latents, channels-last decoded clip [T,512,512,8] in [-1,1]).
+        stage_flops (a dict): receives {"denoise" | "vae" | "recon": {kind: algorithmic FLOPs}} of the matrix-pipe launches each stage
+        issued (ops.FlopMeter; eager launches only) - bench.py's `stage_roofline`."""
         ev = (lambda: _event()) if timings is not None else (lambda: None)
+
+        def meter(stage):   # close the previous stage's meter, open the next one
+            if stage_flops is None:
+                return
+            if ops._meter is not None and getattr(ops._meter, "stage", None):
+                stage_flops[ops._meter.stage] = dict(ops._meter.by_kind)
+            ops.set_flop_meter(None)
+            if stage is not None:
+                m = ops.FlopMeter()
+                m.stage = stage
+                ops.set_flop_meter(m)
+        meter("denoise")
         e0 = ev()
         lat = self.pipe(prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, height=height, width=width,
                         num_frames=num_frames, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
                         latents=latents, generator=generator, output_type="latent")["frames"]
         lat = denormalize_latents(lat)
         e1 = ev()
+        meter("vae")
         wg = getattr(self.pipe.plan, "world", None) if self.pipe.plan is not None else None
-        if wg is not None and wg.world > 1 and lat.shape[3] % wg.world == 0:
+        if self.shard_stages and wg is not None and wg.world > 1 and lat.shape[3] % wg.world == 0:
             clip_cl = self.vae.decode_cl_sharded(lat, wg)      # one clip over the ranks of the scene: H-strips with exchanged halo rows
         else:
             clip_cl = self.vae.decode_cl(lat)
         ff_cl = ops.bilinear_cl(clip_cl, (self.ff_res, self.ff_res), align_corners=False)
         e2 = ev()
+        meter("recon")
+        if not self.shard_stages and getattr(self.stitched_decoder, "recon_group", None) is not None:
+            self.stitched_decoder.recon_group = None
         out = self.stitched_decoder.forward_with_latent(lat, None, train=False, image_cl=ff_cl)
         e3 = ev()
+        meter(None)
         if timings is not None:
             torch.cuda.synchronize()
             timings.denoise_ms, timings.vae_ms, timings.recon_ms = e0.elapsed_time(e1), e1.elapsed_time(e2), e2.elapsed_time(e3)

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import math
 import threading
+from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Dict, Optional
 
@@ -129,7 +130,15 @@ class WanDiT:
         self.dtype = bf16
         self._ws: Dict[tuple, _Workspace] = {}
         self._rope: Dict[tuple, torch.Tensor] = {}
-        self._ctx: Dict[tuple, tuple] = {}  # (B, L, thread) -> (prompt key, persistent cross-attention K / V^T buffers)
+        # (B, L, thread) -> (prompt key, persistent cross-attention K / V^T buffers), least recently used first.  A slot is a prompt context's
+        # BUFFERS (per block: K | V rows, V^T, and with ctx_vo the [B, d, H * 128] V.Wo^T operand - 283 MB per slot at Wan-1.3B, B = 2;
+        # 4.2 GB at Wan-14B), so the cache is bounded: at most `max_ctx_slots` per host thread, and the slots of threads that no longer
+        # exist (seqpar.ThreadWorld ranks of a finished call) are dropped.  An evicted slot's hipGraphs die with it (GraphedWanDiT keys
+        # its graphs by the slot's serial number).
+        self._ctx: "OrderedDict[tuple, tuple]" = OrderedDict()
+        self.max_ctx_slots = 2
+        self._ctx_serial = 0
+        self._ctx_lock = threading.Lock()   # virtual ranks (threads) look up / evict concurrently
         self.merge_padding_keys = True      # see _context
         # "fp8": self-attention on the block-scaled fp8 MFMA (BASELINE config #4; csrc/attention_fp8.hip): q / k (after RMSNorm + RoPE)
         # and V^T are rounded to e4m3 with the unit scales below.  "bf16" (default) is the reference's precision.
@@ -248,7 +257,10 @@ class WanDiT:
         slot = (B, Lt, threading.get_ident())  # per thread: virtual ranks (seqpar.ThreadWorld) hold different prompts
         # identity of the tensor OBJECT (kept alive by the cache entry, so its address cannot be recycled for another prompt's
         # embeddings while the entry is live) + its in-place version counter
-        ent = self._ctx.get(slot)
+        with self._ctx_lock:
+            ent = self._ctx.get(slot)
+            if ent is not None:
+                self._ctx.move_to_end(slot)
         mode = (self.ctx_vo, self.gemm_dtype)   # the cached-context form stores keys with the query norm's weight folded in
         if ent is not None and ent[0][0] is text and ent[0][1] == text._version and ent[0][2] == mode:
             return ent[1]
@@ -259,6 +271,10 @@ class WanDiT:
         H, hd = cfg.num_attention_heads, cfg.attention_head_dim
         nl = len(self.blocks)
         if ent is None:
+            with self._ctx_lock:
+                self._evict_ctx_slots(slot[2])
+                self._ctx_serial += 1
+                serial = self._ctx_serial
             # K | V rows of every block in ONE buffer [B * Lt, L * 2d] (row = context token, columns = (block, k | v, channel)): what
             # the stacked projection writes; ks[l] is the strided [B * Lt, d] view of block l's keys
             kv = torch.zeros(B * Lt, nl * 2 * d, device=self.device, dtype=bf16)
@@ -267,7 +283,7 @@ class WanDiT:
             kbias = torch.zeros(B, Lp, device=self.device, dtype=f32)
             vwo_store = None
         else:
-            ks, vts, kbias, vwo_store, kv = ent[1][0], ent[1][1], ent[1][4], ent[1][9], ent[1][10]
+            ks, vts, kbias, vwo_store, kv, serial = ent[1][0], ent[1][1], ent[1][4], ent[1][9], ent[1][10], ent[1][11]
         if vwo_store is None and self.ctx_vo and hd == 128 and self.gemm_dtype == "bf16":
             # [B, d, H * 128] per block: (V_h Wo_h^T) of the cached-context form, viewed [B, d, H * Lkp] for the prompt's key count
             vwo_store = [torch.empty(B * d * H * 128, device=self.device, dtype=bf16) for _ in self.blocks]
@@ -318,8 +334,26 @@ class WanDiT:
             for li, (b, vt) in enumerate(zip(self.blocks, vts)):   # flash form: V^T per batch item, each at its 64-padded column block
                 for bi in range(B):
                     ops.gemm(b["wv2"], c[bi * Lt: bi * Lt + Lk], b["bv2"], out=vt[:, bi * Lp: bi * Lp + Lk], bias_row=True)
-        self._ctx[slot] = (key, (ks, vts, Lt, Lp, kbias, Lk, merged, vwos, Lkp, vwo_store, kv))
-        return self._ctx[slot][1]
+        val = (ks, vts, Lt, Lp, kbias, Lk, merged, vwos, Lkp, vwo_store, kv, serial)
+        with self._ctx_lock:
+            self._ctx[slot] = (key, val)
+            self._ctx.move_to_end(slot)
+        return val
+
+    def _evict_ctx_slots(self, thread_id: int) -> None:
+        """Make room for one new context slot of `thread_id`: drop the slots of host threads that no longer exist, then the least recently
+        used slots of this thread until fewer than `max_ctx_slots` remain.  (Buffers still referenced by in-flight launches stay alive
+        until the stream has passed them: the caching allocator frees stream-ordered.)"""
+        alive = {t.ident for t in threading.enumerate()}
+        for k in [k for k in self._ctx if k[2] not in alive]:
+            del self._ctx[k]
+        mine = [k for k in self._ctx if k[2] == thread_id]
+        for k in mine[: max(0, len(mine) - (self.max_ctx_slots - 1))]:
+            del self._ctx[k]
+
+    def live_ctx_serials(self) -> set:
+        with self._ctx_lock:
+            return {e[1][11] for e in self._ctx.values()}
 
     # ---------------------------------------------------------------- forward
     @torch.no_grad()
@@ -619,10 +653,14 @@ class GraphedWanDiT:
         if not sp_ok or num_layers is not None or (pr is not None and pr.active):
             return self.dit.forward(hidden_states, timestep, encoder_hidden_states, return_dict, num_layers, sp)
         text = encoder_hidden_states
-        lk = self.dit._context(text)[5]  # eager: refreshes the persistent K / V^T buffers when the prompt changed
+        cx = self.dit._context(text)  # eager: refreshes the persistent K / V^T buffers when the prompt changed
+        lk, serial = cx[5], cx[11]
+        live = self.dit.live_ctx_serials()
+        for k in [k for k in self._graphs if k[-1] not in live]:   # graphs over an evicted context slot replay freed buffers: drop them
+            del self._graphs[k]
         d = self.dit   # the precision modes are baked into a capture: a flipped mode must not replay the old-precision graph
         key = (tuple(hidden_states.shape), tuple(text.shape), lk, threading.get_ident(), d.attn_dtype, d.gemm_dtype, tuple(d.fp8_scales),
-               d.merge_padding_keys, d.ctx_vo, d.fused_qkv, None if sp is None else (id(sp), sp.world, sp.rank, d.sp_kv_split))
+               d.merge_padding_keys, d.ctx_vo, d.fused_qkv, None if sp is None else (id(sp), sp.world, sp.rank, d.sp_kv_split), serial)
         ent = self._graphs.get(key)
         if ent is None:
             sx = torch.empty(hidden_states.shape, device=self.device, dtype=bf16)
@@ -636,10 +674,9 @@ class GraphedWanDiT:
             if sp is not None:
                 # torch.distributed's RCCL watchdog thread polls the events of the eager warm-up's collectives every ~100 ms.  Under the
                 # default GLOBAL capture mode such a query from another thread while this thread captures aborts the process ("operation not
-                # permitted on an event last recorded in a capturing stream": 2 of 12 runs on MI355X / torch 2.10).  Let the watchdog retire
-                # the finished work first and capture thread-locally - either alone measured 0 of 12.
-                import time
-                time.sleep(0.3)
+                # permitted on an event last recorded in a capturing stream": 2 of 12 runs on MI355X / torch 2.10).  THREAD-LOCAL capture makes
+                # the other thread's query legal by definition (it concerns this thread's calls only): 0 of 12 on its own, no timing assumption
+                # (a 0.3 s sleep that let the watchdog retire the warm-up's work first used to sit here as well; it is gone).
                 kw = dict(capture_error_mode="thread_local")
             with torch.cuda.graph(g, **kw):
                 out = self.dit.forward(sx, st, text, sp=sp)[0]
