@@ -37,6 +37,15 @@ def hip_lib():
     return lib.load()
 
 
+@pytest.fixture(scope="session")
+def recon_full(hip_lib):
+    """Width-1024 / 16-head reconstruction weights (tests/fullsize_cases.py::recon_full_weights): (oracle ReconCfg, state dict).  Built once
+    per session - the seeded fp32 generator takes ~20 s of host time - and shared by the full-size and the per-block production tests."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import fullsize_cases as FC
+    return FC.recon_full_weights()
+
+
 class _ParityLog:
     """Measured parity errors of the `-m gpu` tests, written to gpurun_out/parity.json at session end (the builder copies the
     file to profiles/rNN/parity.json so that every tolerance quoted in DESIGN.md has an artifact behind it)."""

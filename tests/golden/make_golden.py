@@ -96,6 +96,29 @@ def stitch_tiny():
     _save("stitch_tiny", {"latent": lat, "weight": layer.weight.detach(), "bias": layer.bias.detach(), "out": ref})
 
 
+def stitch_dilated_grouped():
+    """stitching_layer_builder.py:21-42: `ConvSpec.build(in_channels, groups=)` hands dilation and groups to nn.Conv3d(padding_mode="replicate").
+    Two layers of the reference's own builder on one T-upsampled latent: a dilated one (`_d1x2x2`: the spec grammar's optional field) and a
+    dilated + grouped one (groups = 4).  Inputs, parameters ([Cout, Cin / groups, *k] for the grouped layer) and outputs become the fixture."""
+    from models.stitching_layer_builder import parse_conv_spec
+    g = torch.Generator().manual_seed(41)
+    lat = torch.randn(1, 16, 3, 12, 12, generator=g)
+    T = lat.shape[2]
+    out = {"latent": lat}
+    with torch.no_grad():
+        up = torch.nn.functional.interpolate(lat, size=[(T - 1) * 4 + 1, 12, 12], mode="trilinear", align_corners=True)
+        for name, spec_s, groups in (("dil", "conv3d_k3x3x3_o64_s1x2x2_p1x2x2_d1x2x2", 1), ("dilgrp", "conv3d_k3x3x3_o64_s1x1x1_p2x2x2_d2x2x2", 4)):
+            spec = parse_conv_spec(spec_s)
+            layer = spec.build(in_channels=16, groups=groups)
+            layer.weight.copy_(torch.randn(layer.weight.shape, generator=g) / 12.0)
+            layer.bias.copy_(torch.randn(layer.bias.shape, generator=g) * 0.1)
+            assert layer.padding_mode == "replicate" and layer.groups == groups and tuple(layer.dilation) == tuple(spec.dilation)
+            ref = layer(up)
+            out.update({f"{name}_weight": layer.weight.detach(), f"{name}_bias": layer.bias.detach(), f"{name}_out": ref})
+            print(f"stitch_dilated_grouped: {spec_s} groups {groups}: weight {tuple(layer.weight.shape)} out {tuple(ref.shape)}")
+    _save("stitch_dilated_grouped", out)
+
+
 def _bare(cls):
     import torch.nn as nn
     o = cls.__new__(cls)
@@ -305,6 +328,37 @@ def recon_tiny_conf():
                               "means": gs.means, "opacities": gs.opacities, "scales": gs.scales})
 
 
+def recon_tiny_conf_b2():
+    """recon_tiny_conf with a BATCH of two scenes (b = 2): the reference takes the render_conf quantile over `depth_conf.flatten(0, 1)`
+    WITHOUT a dim (anysplat_stitched.py:381-387) - one threshold spanning the batch - then masks every scene with it and pads the per-scene
+    lists to the larger count (:441-453).  Stores both scenes' inputs, the depth confidences, the batch quantile, the mask, the kept counts and
+    the padded Gaussian means / opacities."""
+    from oracle import recon as R
+    cfg = R.ReconCfg(**RECON_TINY)
+    sd = R.make_recon_weights(cfg, seed=41)
+    model = build_reference_stitched(cfg, sd)
+    model.encoder.cfg.voxelize, model.encoder.cfg.render_conf, model.encoder.cfg.conf_threshold = False, True, 0.25
+    g = torch.Generator().manual_seed(43)
+    S, H, W = 2, 28, 28
+    lat = torch.randn(2, cfg.C, S, H // 14, W // 14, generator=g)
+    lat[1] *= 1.7                                   # a second scene with a different confidence distribution: unequal kept counts
+    img = torch.rand(2, 3, S, H, W, generator=g) * 2 - 1
+    img[1] *= 0.4
+    import contextlib, io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        ref, _anchor, _conf, dconf = model(lat, img, True)
+    q = torch.quantile(dconf.flatten(0, 1), 0.25)
+    mask = dconf > q
+    assert torch.equal(mask, ref.depth_dict["conf_valid_mask"])
+    kept = mask.flatten(1).sum(1)
+    gs = ref.gaussians
+    assert gs.means.shape[:2] == (2, int(kept.max())) and kept[0] != kept[1]
+    per_scene_q = [torch.quantile(dconf[b].flatten(), 0.25).item() for b in range(2)]
+    print(f"recon_tiny_conf_b2: kept {kept.tolist()} of {mask[0].numel()} points per scene; batch quantile {q.item():.6f} (per-scene {per_scene_q})")
+    _save("recon_tiny_conf_b2", {"latent": lat, "image": img, "depth_conf": dconf, "quantile": q.reshape(1), "mask": mask.to(torch.uint8),
+                                 "kept": kept, "means": gs.means, "opacities": gs.opacities, "scales": gs.scales})
+
+
 DENOISE_LOOP_BLOCK_SHA256 = "097e7953bc87ac4d7da05ef37ee830a6a838ba17f9436763f3e9ec6890727a62"   # dedented train_vdm.py:586-624 as reviewed
 
 
@@ -367,7 +421,7 @@ def denoise_loop_ref():
                                "config": torch.tensor([steps, shift, guidance, text_dim], dtype=torch.float64)})
 
 
-GENERATORS = {f.__name__: f for f in [vae_decode_tiny, vae_encode_tiny, stitch_tiny, recon_tiny, recon_mh, recon_tiny_conf, voxel_collide,
+GENERATORS = {f.__name__: f for f in [vae_decode_tiny, vae_encode_tiny, stitch_tiny, stitch_dilated_grouped, recon_tiny, recon_mh, recon_tiny_conf, recon_tiny_conf_b2, voxel_collide,
                                       denoise_loop_ref]}
 
 if __name__ == "__main__":

@@ -434,6 +434,31 @@ def test_prompt_context_cache_survives_address_reuse(tiny):
     assert torch.equal(out, want), f"stale prompt context (address reused: {same_addr})"
 
 
+def test_prompt_context_slots_are_bounded_and_evicted_graphs_are_dropped(tiny):
+    """The per-(batch, prompt length) context buffers are an LRU of `max_ctx_slots` (2) per host thread, not a cache that grows for ever (a slot
+    is 283 MB at Wan-1.3B, 4.2 GB at Wan-14B): a third prompt length evicts the least recently used slot, the evicted length is recomputed
+    correctly when it comes back, and a hipGraph captured over an evicted slot is dropped instead of replayed over freed buffers."""
+    from vist3a_amd.wan.dit import GraphedWanDiT, WanDiT, WanDiTConfig
+    ocfg, sd, _ = tiny
+    model = WanDiT(WanDiTConfig(**TINY), sd, device="cuda")
+    gm = GraphedWanDiT(model)
+    g = torch.Generator().manual_seed(34)
+    lat = torch.randn(2, 16, 2, 16, 16, generator=g).to(torch.bfloat16).cuda()
+    t = torch.tensor([700, 700]).cuda()
+    texts = {n: (torch.randn(2, n, ocfg.text_dim, generator=g) * 0.5).cuda() for n in (40, 64, 96)}
+    first = {n: gm(lat, t, texts[n])[0].clone() for n in (40, 64)}
+    assert len(model._ctx) == 2 and len(gm._graphs) == 2
+    serial40 = model._ctx[next(k for k in model._ctx if k[1] == 40)][1][11]
+    out96 = gm(lat, t, texts[96])[0].clone()                      # third length: evicts the slot of length 40 (least recently used)
+    assert len(model._ctx) == 2 and {k[1] for k in model._ctx} == {64, 96}
+    assert len(gm._graphs) == 2 and all(k[-1] != serial40 for k in gm._graphs)      # ... and its graph with it
+    assert torch.equal(out96, model(lat, t, texts[96])[0])        # graph replay == eager
+    again = gm(lat, t, texts[40])[0].clone()                      # the evicted length comes back: new slot, new capture, same result
+    assert torch.equal(again, first[40]) and {k[1] for k in model._ctx} == {96, 40}
+    assert torch.equal(gm(lat, t, texts[96])[0], out96)
+    assert model.max_ctx_slots == 2
+
+
 def test_merged_padding_keys_equal_full_cross_attention(tiny):
     """Zero-padded prompt: cross-attention over n real keys + ONE padding key with bias log(count) == attention over all 512 keys
     (exact in real arithmetic; bf16 P rounding differs: 2e-3), and an unpadded prompt takes the plain path."""

@@ -73,10 +73,8 @@ def test_full_size_vae_decode_matches_oracle(hip_lib, parity):
 VAE_FULL_GATE = 2.9e-2    # <= 2x the measured HIP-vs-contract figure (1.48e-2 on MI355X, profiles/r4/parity.json)
 
 
-@pytest.fixture(scope="module")
-def recon_full(hip_lib):
-    """Width-1024 / 16-head reconstruction weights (tests/fullsize_cases.py::recon_full_weights)"""
-    return FC.recon_full_weights()
+# (`recon_full`: the width-1024 / 16-head reconstruction weights, a session fixture of tests/conftest.py shared with
+#  tests/test_production_blocks_gpu.py)
 
 
 def _stitched(sd, rcfg_kw, C, res=512):

@@ -25,6 +25,26 @@ def test_conv_spec_grammar():
     assert tuple(layer.weight.shape) == (1024, 16, 5, 3, 3) and layer.padding_mode == "replicate"
 
 
+def test_grouped_dilated_stitching_layer_holder():
+    """`ConvSpec.build(in_channels, groups=)` (stitching_layer_builder.py:21-42): nn.Conv's parameter layout [Cout, Cin / groups, *k], its
+    divisibility error, and a dense block-diagonal form that is the same linear map as the grouped convolution."""
+    from vist3a_amd.models.stitching_layer_builder import parse_conv_spec
+    spec = parse_conv_spec("conv3d_k3x3x3_o32_s1x2x2_p2x2x2_d2x2x2")
+    assert spec.dilation == (2, 2, 2)
+    layer = spec.build(in_channels=16, groups=4)
+    assert tuple(layer.weight.shape) == (32, 4, 3, 3, 3) and layer.groups == 4 and layer.dilation3 == (2, 2, 2) and layer.padding_mode == "replicate"
+    x = torch.randn(1, 16, 5, 9, 9, generator=torch.Generator().manual_seed(0))
+    F = torch.nn.functional
+    xp = F.pad(x, (2, 2, 2, 2, 2, 2), mode="replicate")
+    want = F.conv3d(xp, layer.weight, layer.bias, stride=(1, 2, 2), dilation=2, groups=4)
+    got = F.conv3d(xp, layer.dense_weight(), layer.bias, stride=(1, 2, 2), dilation=2)
+    assert torch.allclose(got, want, atol=1e-5)
+    plain = spec.build(16)
+    assert plain.dense_weight() is not None and torch.equal(plain.dense_weight(), plain.weight.detach())      # groups = 1: the weight itself
+    with pytest.raises(ValueError):
+        spec.build(in_channels=18, groups=4)
+
+
 def test_cli_flags_match_reference_surface():
     from vist3a_amd.utils.argument import inference_vist3a_argument, parse_lora_mode
     a = inference_vist3a_argument().parse_args(["--checkpoint_path", "c", "--transformer_lora_path", "l", "--input_texts_path", "t"])

@@ -486,6 +486,30 @@ def test_stitching_conv_matches_reference_golden(hip_lib, parity):
     assert r < 6e-3, r   # bf16 latent clip and bf16 weights against the reference's fp32 layer
 
 
+def test_dilated_and_grouped_stitching_conv_matches_reference_golden(hip_lib, parity):
+    """/root/reference/models/stitching_layer_builder.py:21-42 builds dilated (`_d..` of the spec grammar) and grouped (`build(groups=)`) layers;
+    tests/golden/stitch_dilated_grouped.safetensors holds the outputs of two such layers of the reference's own builder.  Ours: the same
+    spec strings through `parse_conv_spec(..).build(..)`, the checkpoint's [Cout, Cin / groups, *k] parameters assigned into the holder, the
+    packed weight the stitched model makes of it (dilated taps in the K-chunk table, block-diagonal dense weight), v3a_conv_bf16."""
+    from vist3a_amd import ops
+    from vist3a_amd.models.stitching_layer_builder import parse_conv_spec
+    gold = load_file(str(G / "stitch_dilated_grouped.safetensors"))
+    lat_cl = ops.latent_upsample_t_cl(gold["latent"][0].to(dev).contiguous())
+    errs = {}
+    for name, spec_s, groups in (("dil", "conv3d_k3x3x3_o64_s1x2x2_p1x2x2_d1x2x2", 1), ("dilgrp", "conv3d_k3x3x3_o64_s1x1x1_p2x2x2_d2x2x2", 4)):
+        layer = parse_conv_spec(spec_s).build(in_channels=16, groups=groups)
+        assert tuple(layer.weight.shape) == tuple(gold[f"{name}_weight"].shape)              # nn.Conv3d's parameter layout
+        layer.weight.data, layer.bias.data = gold[f"{name}_weight"], gold[f"{name}_bias"]
+        cw = ops.ConvWeight(layer.dense_weight(), layer.bias.detach(), dilation=layer.dilation3)
+        y = ops.conv(lat_cl, cw, stride=layer.stride3, pad=layer.padding3, replicate=True, out_f32=True)
+        got = y.permute(3, 0, 1, 2)[None].float().cpu()
+        assert got.shape == gold[f"{name}_out"].shape, (got.shape, gold[f"{name}_out"].shape)
+        errs[name] = relerr(got, gold[f"{name}_out"])
+    parity("stitch_conv_dilated_grouped_vs_reference_golden", **errs)
+    print("dilated / grouped stitching conv vs reference golden", errs)
+    assert max(errs.values()) < 6e-3, errs   # bf16 latent clip and bf16 weights against the reference's fp32 layer (stitch_tiny: the same bar)
+
+
 # ---------------------------------------------------------------- resize / norms ----
 def test_bilinear_cl_512_to_448_matches_interpolate(hip_lib, parity):
     """V8: F.interpolate(size=448, mode="bilinear", align_corners=False) on the decoded 13 x 512^2 clip (t23d.py)."""

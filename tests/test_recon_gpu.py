@@ -311,6 +311,52 @@ def test_boundary_conf_valid_mask_matches_reference_golden(hip_lib):
     assert bool(out_n.depth_dict["conf_valid_mask"].all()) and out_n.depth_dict["conf_valid_mask"].shape == ref_mask.shape
 
 
+def test_render_conf_quantile_spans_the_batch_like_the_reference(hip_lib, parity):
+    """b = 2 with render_conf (anysplat_stitched.py:381-387): `torch.quantile(depth_conf.flatten(0, 1), t)` has no dim - ONE threshold over
+    both scenes - against tests/golden/recon_tiny_conf_b2.safetensors, the reference's own b = 2 forward (kept counts 1297 / 1055 of 1568:
+    per-scene quantiles would keep 1176 / 1176).  (a) on the reference's own confidences the batch assembly's threshold, mask and kept rows
+    are exact; (b) end to end the mask agrees up to the bf16 noise of the confidences and the Gaussians are the mask's rows, padded."""
+    from safetensors.torch import load_file
+    from pathlib import Path
+    from vist3a_amd import ops
+    from vist3a_amd.models.anysplat_stitched import AnySplatStitched, AnySplatWeights
+    from vist3a_amd.recon.engine import ReconCfg
+    g = load_file(str(Path(__file__).parent / "golden" / "recon_tiny_conf_b2.safetensors"))
+    kw = dict(C=64, heads=1, n_dino=22, depth=24, cam_heads=2, cam_trunk=2, features=32, oc=(16, 32, 64, 64))
+    sd = R.make_recon_weights(R.ReconCfg(**kw), seed=41)
+    m = AnySplatStitched(AnySplatWeights(dict(sd), ReconCfg(**kw, voxelize=False, render_conf=True, conf_threshold=0.25)), "enc_blocks_2", "cuda")
+    ref_mask, kept = g["mask"].bool(), g["kept"].tolist()
+    # (a) the assembly on the reference's confidences: exact
+    conf = g["depth_conf"].cuda()
+    B, S, H, W = conf.shape
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    outs = [dict(depth_conf=conf[b].reshape(-1).contiguous(), pts_all=torch.randn(S * H * W, 3, device="cuda", generator=gen),
+                 raw_gs=torch.randn(S * H * W, 84, device="cuda", generator=gen)) for b in range(B)]
+    c = ops.conf_quantile_compact(torch.cat([o["depth_conf"] for o in outs]), 0.25, torch.cat([o["pts_all"] for o in outs]),
+                                  torch.cat([o["raw_gs"] for o in outs]), 83)
+    assert torch.equal(c["threshold"].cpu().reshape(1), g["quantile"])
+    assert torch.equal((conf > c["threshold"]).cpu(), ref_mask) and c["pts"].shape[0] == sum(kept)
+    # (b) end to end
+    out, anchor, gconf, dconf = m(g["latent"].cuda(), g["image"].cuda(), train=True)
+    mask = out.depth_dict["conf_valid_mask"]
+    mine = mask.view(B, -1).sum(1).tolist()
+    rel = ((dconf.float().cpu() - g["depth_conf"]).norm() / g["depth_conf"].norm()).item()
+    agree = (mask.cpu() == ref_mask).float().mean().item()
+    parity("render_conf_batch2_vs_reference_golden", depth_conf_rel=rel, mask_agreement=agree, kept=mine, kept_reference=kept)
+    print(f"render_conf b=2: kept {mine} vs reference {kept}; depth_conf rel {rel:.2e}; mask agreement {agree:.4f}")
+    assert mask.shape == ref_mask.shape and mask.dtype == torch.bool
+    assert abs(sum(mine) - sum(kept)) <= 1                                  # the batch quantile fixes the TOTAL kept count (ties aside)
+    assert all(abs(a - b) <= 0.03 * b for a, b in zip(mine, kept)), (mine, kept)     # per-scene shares move with the bf16 noise of the confidences
+    assert mine[0] != mine[1] and agree > 0.97 and rel < 1.7e-2
+    U = max(mine)
+    assert out.gaussians.means.shape[:2] == (B, U)
+    for b in range(B):                                                      # the Gaussians ARE the mask's rows; the shorter scene is padded with opacity 0
+        assert bool((out.gaussians.opacities[b, mine[b]:] == 0).all())
+    # a b = 1 call of the same model still takes its own scene's quantile
+    one = m(g["latent"][:1].cuda(), g["image"][:1].cuda(), train=False)
+    assert int(one.depth_dict["conf_valid_mask"].sum()) == one.gaussians.means.shape[1] != mine[0]
+
+
 def test_batched_forward_assembles_scenes_like_the_reference(hip_lib):
     """AnySplatStitched.forward with b = 2 (anysplat_stitched.py:174-202, 417-453): every scene's slice equals its own b = 1 forward bit
     for bit; the scene with fewer voxels is padded to the larger count with rows whose opacity is exactly 0 (features -1e10 -> density

@@ -131,14 +131,27 @@ class AnySplatStitched(torch.nn.Module):
         """b > 1 (anysplat_stitched.py:174-202 folds (b v) into the token batch; every scene is still reconstructed on its own views): one
         engine forward per scene, then the reference's batch assembly - per-scene voxel lists padded to the largest count with features
         -1e10 / points -1e4 (:440-453: a padded row has density sigmoid(-1e10) = 0, i.e. opacity 0), the Gaussian adapter over the padded
-        rows, `scene_scale` taken over the whole batch (:411-412).  The reference takes the `render_conf` quantile over the whole batch as
-        well (:381-387); that branch is not assembled here."""
+        rows, `scene_scale` taken over the whole batch (:411-412).  The `render_conf` quantile spans the batch as well (:381-387:
+        `torch.quantile(depth_conf.flatten(0, 1), t)` has no `dim`): the per-scene forwards leave it to `assemble_batch`."""
         eng = self.engine()
-        if eng.cfg.render_conf:
-            raise NotImplementedError("render_conf with batch > 1: the reference's confidence quantile spans the batch")
         B, _, S, H, W = context_image.shape
-        outs = [self.keep_scene(eng.forward(context_latent[b:b + 1], context_image[b:b + 1])) for b in range(B)]
+        with self.scenes_of_a_batch():
+            outs = [self.keep_scene(eng.forward(context_latent[b:b + 1], context_image[b:b + 1])) for b in range(B)]
         return self.assemble_batch(outs, S, H, W, train)
+
+    def scenes_of_a_batch(self):
+        """context manager around the per-scene engine forwards of a b > 1 call: the engine skips its per-scene confidence quantile"""
+        import contextlib
+        eng = self.engine()
+
+        @contextlib.contextmanager
+        def cm():
+            prev, eng.batch_conf = eng.batch_conf, True
+            try:
+                yield
+            finally:
+                eng.batch_conf = prev
+        return cm()
 
     _KEEP = ("pred_pose_enc_list", "depth", "depth_conf", "pts_all", "raw_gs", "extrinsic_w2c", "intrinsic_px", "neural_pts", "neural_feats")
 
@@ -151,9 +164,22 @@ class AnySplatStitched(torch.nn.Module):
         """per-scene engine outputs (keep_scene) -> the reference's batched EncoderOutput (anysplat_stitched.py:411-525)"""
         from .. import ops
         eng = self.engine()
-        if eng.cfg.render_conf:
-            raise NotImplementedError("render_conf with batch > 1: the reference's confidence quantile spans the batch")
         B = len(outs)
+        valid = None
+        if eng.cfg.render_conf:
+            # anysplat_stitched.py:381-387: ONE threshold = the quantile of every scene's depth confidences together, then each scene's own mask;
+            # without the voxel branch the kept rows (boolean-mask order = row-major, :441-446) are the scene's Gaussians.  One device
+            # sort + compaction over the concatenated maps (v3a_conf_quantile_compact: exact fp32 rank up to 2^24 pixels per batch).
+            M = S * H * W
+            gsd = outs[0]["neural_feats"].shape[1]
+            conf_all = torch.cat([o["depth_conf"].reshape(M) for o in outs]).contiguous()
+            c = ops.conf_quantile_compact(conf_all, eng.cfg.conf_threshold, torch.cat([o["pts_all"].reshape(M, 3) for o in outs]),
+                                          torch.cat([o["raw_gs"] for o in outs]), gsd)
+            valid = torch.stack([o["depth_conf"].reshape(S, H, W) for o in outs], 0) > c["threshold"]
+            if not eng.cfg.voxelize:
+                kept = valid.view(B, -1).sum(1).tolist()
+                for o, p_, f_ in zip(outs, torch.split(c["pts"], kept), torch.split(c["feat"], kept)):
+                    o["neural_pts"], o["neural_feats"] = p_, f_
         U = max(o["neural_feats"].shape[0] for o in outs)
         dev = outs[0]["neural_feats"].device
         gs = []
@@ -174,7 +200,7 @@ class AnySplatStitched(torch.nn.Module):
         poses = [torch.stack([o["pred_pose_enc_list"][i] for o in outs], 0) for i in range(len(outs[0]["pred_pose_enc_list"]))]
         scale = torch.stack([o["pts_all"].reshape(-1, 3) for o in outs], 0).norm(dim=-1).mean().clip(min=1e-8)
         eo = EncoderOutput(gaussians=gauss, pred_pose_enc_list=poses, pred_context_pose=pose,
-                           depth_dict=dict(depth=depth, conf_valid_mask=torch.ones_like(dconf, dtype=torch.bool)),
+                           depth_dict=dict(depth=depth, conf_valid_mask=valid if valid is not None else torch.ones_like(dconf, dtype=torch.bool)),
                            infos=dict(scene_scale=scale, voxelize_ratio=U / (H * W * S)), distill_infos=None,
                            last_pred_pose_enc=None if train else poses[-1])
         if not train:

@@ -48,9 +48,11 @@ class StitchVAE3D(torch.nn.Module):
         w, b = self.stitching_layer.weight, self.stitching_layer.bias
         key = (w._version, w.data_ptr(), None if b is None else (b._version, b.data_ptr()))
         if self._packed is None or key != self._packed_key:
-            wd = w.detach()
+            st = self.stitching_layer
+            wd = st.dense_weight() if hasattr(st, "dense_weight") else w.detach()      # (grouped layers: their block-diagonal dense form)
             wd = wd.reshape(wd.shape[0], wd.shape[1], *((1,) * (5 - wd.dim())), *wd.shape[2:]) if wd.dim() < 5 else wd
-            self._packed, self._packed_key = ops.ConvWeight(wd, None if b is None else b.detach(), device=self.device), key
+            self._packed, self._packed_key = ops.ConvWeight(wd, None if b is None else b.detach(), device=self.device,
+                                                            dilation=getattr(st, "dilation3", (1, 1, 1))), key
         return self._packed
 
     @torch.no_grad()
@@ -87,10 +89,11 @@ class StitchVAE3D(torch.nn.Module):
                 raise ValueError("latent and feedforward_image disagree on the batch size")
             model = self.stitched_3d_model
             outs, shp = [], None
-            for b in range(B):
-                o, shp = self._scene(latent[b:b + 1], None if feedforward_image is None else feedforward_image[b:b + 1],
-                                     None if image_cl is None else image_cl[b], grp)
-                outs.append(model.keep_scene(o))
+            with model.scenes_of_a_batch():     # (the render_conf quantile spans the batch: taken in assemble_batch)
+                for b in range(B):
+                    o, shp = self._scene(latent[b:b + 1], None if feedforward_image is None else feedforward_image[b:b + 1],
+                                         None if image_cl is None else image_cl[b], grp)
+                    outs.append(model.keep_scene(o))
             return model.assemble_batch(outs, *shp, train)
         out, (S, H, W) = self._scene(latent, feedforward_image, image_cl, grp)
         return self.stitched_3d_model.package(out, S, H, W, train)
@@ -115,7 +118,7 @@ class StitchVAE3D(torch.nn.Module):
         x, g = (None, eng.geometry_constants(S, H, W)) if sharded else eng.token_workspace(S, H, W)
         hw, Pp, nsp = g["hw"], g["Pp"], g["nsp"]
         cw = self._conv_weight()
-        oshape = [(lat_cl.shape[i] + 2 * st.padding3[i] - st.kernel3[i]) // st.stride3[i] + 1 for i in range(3)]
+        oshape = [(lat_cl.shape[i] + 2 * st.padding3[i] - cw.k_eff[i]) // st.stride3[i] + 1 for i in range(3)]
         if oshape[0] != S or oshape[1] * oshape[2] != hw or cw.CoutP != eng.cfg.C:
             raise ValueError(f"stitching layer output {oshape}x{cw.Cout} does not match the {S}x{g['hp']}x{g['wp']}x{eng.cfg.C} token grid")
         if grp is not None and grp.world > 1:

@@ -3,7 +3,9 @@
 Same grammar, defaults and error behaviour as /root/reference/models/stitching_layer_builder.py:48-89
 (`parse_conv_spec` -> `ConvSpec`; ValueError on a malformed string); `ConvSpec.build(in_channels)` returns the parameter
 holder the checkpoint loader assigns into (`.weight`, `.bias`: /root/reference/evaluation/novel_view_synthesis_bench/nvs_eval.py:51-52).
-The convolution itself (padding_mode="replicate", :39) runs in v3a_conv_bf16."""
+The convolution itself (padding_mode="replicate", :39) runs in v3a_conv_bf16 - dilated specs (`_d2`, `_d1x2x2`) through scaled tap offsets
+of its K-chunk table, grouped layers (`build(..., groups=g)`, :21-42) as the block-diagonal dense weight they are (the zero blocks add
+exact zeros; the layer is 2e10 FLOP)."""
 from __future__ import annotations
 
 import math
@@ -32,20 +34,38 @@ def _triple(v: IntOrTuple, dim: int) -> Tuple[int, int, int]:
 class StitchingConv(torch.nn.Module):
     """Parameter holder for the stitching convolution (weight [Cout, Cin, *k], bias [Cout]); nn.Conv default init."""
 
-    def __init__(self, spec: "ConvSpec", in_channels: int, bias: bool = True):
+    def __init__(self, spec: "ConvSpec", in_channels: int, bias: bool = True, groups: int = 1):
         super().__init__()
         k = spec.kernel_size if not isinstance(spec.kernel_size, int) else (spec.kernel_size,) * spec.dim
-        self.spec, self.in_channels, self.out_channels = spec, in_channels, spec.out_channels
+        if groups < 1 or in_channels % groups or spec.out_channels % groups:
+            raise ValueError("in_channels and out_channels must be divisible by groups")      # nn.Conv's own check and wording
+        self.spec, self.in_channels, self.out_channels, self.groups = spec, in_channels, spec.out_channels, groups
         self.padding_mode = "replicate"
-        w = torch.empty(spec.out_channels, in_channels, *k)
+        w = torch.empty(spec.out_channels, in_channels // groups, *k)     # nn.Conv layout: [Cout, Cin / groups, *k]
         torch.nn.init.kaiming_uniform_(w, a=math.sqrt(5))
         self.weight = torch.nn.Parameter(w)
-        bound = 1 / math.sqrt(in_channels * math.prod(k))
+        bound = 1 / math.sqrt(in_channels // groups * math.prod(k))
         self.bias = torch.nn.Parameter(torch.empty(spec.out_channels).uniform_(-bound, bound)) if bias else None
 
     @property
     def kernel3(self):
         return _triple(self.spec.kernel_size, self.spec.dim)
+
+    @property
+    def dilation3(self):
+        return _triple(self.spec.dilation, self.spec.dim)
+
+    def dense_weight(self) -> torch.Tensor:
+        """[Cout, Cin, *k]: the weight as it is for groups = 1; for a grouped layer the block-diagonal dense form (output channels of group j
+        see the input channels of group j only, zeros elsewhere) - the same map, runnable by the dense implicit-GEMM convolution"""
+        w = self.weight.detach()
+        if self.groups == 1:
+            return w
+        co, ci = self.out_channels // self.groups, self.in_channels // self.groups
+        d = torch.zeros(self.out_channels, self.in_channels, *w.shape[2:], dtype=w.dtype, device=w.device)
+        for j in range(self.groups):
+            d[j * co:(j + 1) * co, j * ci:(j + 1) * ci] = w[j * co:(j + 1) * co]
+        return d
 
     @property
     def stride3(self):
@@ -67,9 +87,7 @@ class ConvSpec:
     dilation: IntOrTuple = 1
 
     def build(self, in_channels: int, bias: bool = True, groups: int = 1) -> StitchingConv:
-        if groups != 1 or self.dilation not in (1, (1,) * self.dim):
-            raise NotImplementedError("grouped / dilated stitching layers are not used on the VIST3A path")
-        return StitchingConv(self, int(in_channels), bias)
+        return StitchingConv(self, int(in_channels), bias, int(groups))
 
 
 def parse_conv_spec(spec: str) -> ConvSpec:

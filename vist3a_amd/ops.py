@@ -286,7 +286,9 @@ class ConvWeight:
     """A convolution weight packed for v3a_conv_bf16: w[CoutPad][Kpad] bf16 (k = tap-major, channel-minor), the
     K-chunk table, f32 bias.  Cin/Cout are padded to multiples of 8 with zeros (activations must carry CinPad)."""
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device="cuda"):
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, device="cuda", dilation=(1, 1, 1)):
+        """dilation (dT, dH, dW): tap (t, h, w) reads the input t dT / h dH / w dW positions from the window origin - the K-chunk table
+        carries the scaled offsets (4 bits each: (k - 1) d <= 15), the kernels are unchanged; `k_eff` is the window extent (k - 1) d + 1."""
         w = weight.detach()
         if w.dim() == 4:  # conv2d -> kT = 1
             w = w[:, :, None]
@@ -294,6 +296,10 @@ class ConvWeight:
             w = w[:, :, None, None]
         Cout, Cin, kT, kH, kW = w.shape
         self.Cout, self.Cin, self.k = Cout, Cin, (kT, kH, kW)
+        self.dil = tuple(int(v) for v in dilation)
+        if len(self.dil) != 3 or min(self.dil) < 1 or any((k - 1) * d_ > 15 for k, d_ in zip(self.k, self.dil)):
+            raise ValueError(f"dilation {dilation} with kernel {self.k}: every (k - 1) * d must be <= 15 (4-bit tap offsets of the K-chunk table)")
+        self.k_eff = tuple((k - 1) * d_ + 1 for k, d_ in zip(self.k, self.dil))
         self.CinP, self.CoutP = (Cin + 7) // 8 * 8, (Cout + 7) // 8 * 8
         K = kT * kH * kW * self.CinP
         self.Kpad = (K + 63) // 64 * 64
@@ -305,7 +311,7 @@ class ConvWeight:
         tab = torch.zeros(self.Kpad // 8, dtype=torch.int64)
         idx = torch.arange(K // 8)
         tap, c8 = idx // (self.CinP // 8), idx % (self.CinP // 8)
-        dt, dh, dw = tap // (kH * kW), (tap // kW) % kH, tap % kW
+        dt, dh, dw = tap // (kH * kW) * self.dil[0], (tap // kW) % kH * self.dil[1], tap % kW * self.dil[2]
         tab[: K // 8] = (c8 * 8) | (dw << 16) | (dh << 20) | (dt << 24) | (1 << 31)
         tab = torch.where(tab >= 2 ** 31, tab - 2 ** 32, tab)
         self.ktab = tab.to(torch.int32).to(device).contiguous()
@@ -317,7 +323,7 @@ class ConvWeight:
         # second packing for the halo-tile kernel (csrc/conv_halo.hip; layout documented at v3a_conv_args.w_halo):
         # [Cout/96][kT][Cin/48][9][96][48], the six 16-byte chunks of row n rotated by 3 * ((n >> 3) & 1)
         self.w_halo = None
-        if kH == 3 and kW == 3 and kT in (1, 3) and self.CinP % 48 == 0 and self.CoutP % 96 == 0:
+        if kH == 3 and kW == 3 and kT in (1, 3) and self.CinP % 48 == 0 and self.CoutP % 96 == 0 and self.dil == (1, 1, 1):
             nN, nC = self.CoutP // 96, self.CinP // 48
             h = wp.reshape(nN, 96, kT, 9, nC, 6, 8).permute(0, 2, 4, 3, 1, 5, 6).contiguous()   # [nN, kT, nC, 9, 96, 6 chunks, 8]
             rot = 3 * ((torch.arange(96) >> 3) & 1)
@@ -349,14 +355,15 @@ def conv(
     if Cin != cw.CinP:
         raise ValueError(f"x has {Cin} channels, packed weight expects {cw.CinP}")
     kT, kH, kW = cw.k
+    eT_, eH_, eW_ = cw.k_eff                      # window extents (= the kernel sizes without dilation)
     eH, eW = (2 * H, 2 * W) if ups2 else (H, W)
     if out_size is None:
-        if kT > 1 and pad[0] == kT - 1:
-            oT = (T + pad[0] - kT) // stride[0] + 1
+        if kT > 1 and pad[0] == eT_ - 1:
+            oT = (T + pad[0] - eT_) // stride[0] + 1
         else:
-            oT = (T + 2 * pad[0] - kT) // stride[0] + 1
-        oH = (eH + 2 * pad[1] - kH) // stride[1] + 1
-        oW = (eW + 2 * pad[2] - kW) // stride[2] + 1
+            oT = (T + 2 * pad[0] - eT_) // stride[0] + 1
+        oH = (eH + 2 * pad[1] - eH_) // stride[1] + 1
+        oW = (eW + 2 * pad[2] - eW_) // stride[2] + 1
     else:
         oT, oH, oW = out_size
     M = oT * oH * oW

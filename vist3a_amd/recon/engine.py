@@ -196,6 +196,7 @@ class ReconEngine:
             m[d ** 2:(d + 1) ** 2] = 0.1 * 0.25 ** d
         self.sh_mask = m.to(dev)
         self._geo: Dict[tuple, dict] = {}
+        self.batch_conf = False     # True while the scenes of a batch run one by one: the render_conf quantile is the batch assembly's (see _tail)
 
     # ------------------------------------------------------------------ per-resolution constants / workspaces
     def geometry_constants(self, S, H, W):
@@ -282,14 +283,20 @@ class ReconEngine:
         ops.gemm(g["n"], blk.w1, blk.b1, out=g["h"], act=L.ACT_GELU_ERF)
         ops.gemm(g["h"], blk.w2, blk.b2, out=xo, residual=xo, scale=blk.ls2, round_after_scale=True, out_f32=f)
 
-    def backbone(self, g, S, shard=None):
-        """x (bf16 tokens incl. DINO specials) -> tapped [M, 2C] f32 intermediates.  `shard` (forward_sharded): S = this rank's views."""
+    def backbone(self, g, S, shard=None, hook=None):
+        """x (bf16 tokens incl. DINO specials) -> tapped [M, 2C] f32 intermediates.  `shard` (forward_sharded): S = this rank's views.
+        hook(kind, index, "in" | "out", buffer) (tests): called with the LIVE residual-stream buffer in front of and behind every block
+        (kind in "dino" / "frame" / "global"; rows in the padded [S, Pp, .] layout, row stride = buffer.stride(0)) - the production
+        forward's own stream, for per-block teacher-forced comparisons; the callee copies what it wants to keep."""
+        hk = hook if hook is not None else (lambda *a: None)
         cfg = self.cfg
         C, Pp, nsp = cfg.C, g["Pp"], g["nsp"]
         x, xf = g["x"], g["xf"]
         x.view(S, Pp, C)[:, :nsp] = g["special_dino"]
-        for blk in self.dino:
+        for i, blk in enumerate(self.dino):
+            hk("dino", i, "in", x)
             self._block(g, blk, x, S, False, False, 1e-6)
+            hk("dino", i, "out", x)
         ops.layernorm(x, out=xf, weight=self.dino_nw, bias=self.dino_nb, eps=1e-6)
         xf.view(S, Pp, C)[:, :nsp] = g["special_agg"] if shard is None else shard["special_agg"]
         # The residual stream walks THROUGH the tap buffers (anysplat_stitched.py:249-325 concatenates the frame and global intermediates
@@ -299,10 +306,14 @@ class ReconEngine:
         for li in range(cfg.depth):
             tap = li in cfg.taps
             dst = g["taps"][ti][:, :C] if tap else xf
+            hk("frame", li, "in", cur)
             self._block(g, self.frame[li], cur, S, False, True, 1e-5, xo=dst)
+            hk("frame", li, "out", dst)
             cur = dst
             dst = g["taps"][ti][:, C:] if tap else xf
+            hk("global", li, "in", cur)
             self._block(g, self.glob[li], cur, S, True, True, 1e-5, xo=dst, shard=shard)
+            hk("global", li, "out", dst)
             cur = dst
             ti += int(tap)
         return g["taps"]
@@ -491,9 +502,11 @@ class ReconEngine:
         out = dict(pred_pose_enc_list=poses, depth=depth, depth_conf=dconf, pts_all=pts, raw_gs=raw_gs, extrinsic_w2c=ext, intrinsic_px=K)
         M = S * H * W
         c = None
-        if cfg.render_conf:
+        if cfg.render_conf and not self.batch_conf:
             # the reference takes the quantile whenever render_conf is set (anysplat_stitched.py:381-387), also when the
-            # voxel branch then ignores the mask for the Gaussians: depth_dict["conf_valid_mask"] is returned either way (:494)
+            # voxel branch then ignores the mask for the Gaussians: depth_dict["conf_valid_mask"] is returned either way (:494).
+            # (`batch_conf`: this scene is one of a batch - the quantile spans the batch and is taken by the batch assembly,
+            # models/anysplat_stitched.py::assemble_batch, from the per-pixel maps returned here.)
             c = ops.conf_quantile_compact(dconf.reshape(M), cfg.conf_threshold, pts.view(M, 3), raw_gs, gsd)
             out["conf_valid"] = c["threshold"]
         if cfg.voxelize:

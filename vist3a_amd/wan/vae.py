@@ -54,12 +54,21 @@ class _Res:
         self.c1, self.c2 = cw("conv1"), cw("conv2")
         self.sc = cw("conv_shortcut") if p + "conv_shortcut.weight" in sd else None
 
-    def __call__(self, x):
+    def __call__(self, x, hook=None):
+        """hook(point, tensor) (tests): the block's own tensors at its four bf16 rounding points - "n1" = SiLU(RMS-norm(x)), "y1" = conv1,
+        "n2" = SiLU(RMS-norm(y1)), "out" = conv2 + shortcut - and "in" / "skip" (the input and the shortcut branch)"""
+        hk = hook if hook is not None else (lambda *a: None)
         h = x if self.sc is None else ops.conv(x, self.sc)
+        hk("in", x); hk("skip", h)
         n = ops.rownorm_act(x, self.g1, mode=1, act=L.ACT_SILU)
+        hk("n1", n)
         y = ops.conv(n, self.c1, pad=(2, 1, 1))
+        hk("y1", y)
         n = ops.rownorm_act(y, self.g2, mode=1, act=L.ACT_SILU)
-        return ops.conv(n, self.c2, pad=(2, 1, 1), residual=h)
+        hk("n2", n)
+        o = ops.conv(n, self.c2, pad=(2, 1, 1), residual=h)
+        hk("out", o)
+        return o
 
 
 class _Attn:
@@ -231,9 +240,11 @@ class WanVAEDecoder:
         return gb.view(P, T, h, W, y.shape[-1]).permute(1, 0, 2, 3, 4).reshape(T, P * h, W, y.shape[-1]).contiguous()
 
     @torch.no_grad()
-    def decode_cl(self, z: torch.Tensor) -> torch.Tensor:
+    def decode_cl(self, z: torch.Tensor, hook=None) -> torch.Tensor:
         """Same decode, result left channels-last [T, 8h, 8w, 8] bf16 (RGB in channels 0-2, clamped to [-1,1]) — the layout
-        the resize kernel and the reconstruction heads consume, so the decoded clip never takes an NCHW round trip."""
+        the resize kernel and the reconstruction heads consume, so the decoded clip never takes an NCHW round trip.
+        hook(name, point, tensor) (tests): every up-block residual block's tensors (`_Res.__call__`), name = "up_blocks.i.resnets.j" - the
+        production decode's own stream, for per-layer teacher-forced comparisons."""
         if z.dim() != 5 or z.shape[0] != 1:
             raise ValueError("expected z [1, z_dim, T, h, w]")
         x = z[0].permute(1, 2, 3, 0).to(device=self.device, dtype=bf16).contiguous()  # [T,h,w,16]
@@ -242,9 +253,9 @@ class WanVAEDecoder:
         x = self.mid0(x)
         x = self.attn(x)
         x = self.mid1(x)
-        for res, mode, rs, tc, C in self.ups:
-            for r in res:
-                x = r(x)
+        for i, (res, mode, rs, tc, C) in enumerate(self.ups):
+            for j, r in enumerate(res):
+                x = r(x, None if hook is None else (lambda pt, t, nm=f"up_blocks.{i}.resnets.{j}": hook(nm, pt, t)))
             if mode is None:
                 continue
             x = self._upsample(x, mode, rs, tc)
