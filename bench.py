@@ -335,7 +335,7 @@ def main():
     dom_tile = lib.load().v3a_gemm_fp8_pick_tile(2 * N, cfg.dim) if f8 else lib.load().v3a_gemm_pick_tile(2 * N, cfg.dim)
     # every 7th launch of the symbol is bracketed by events.  Per DiT block the symbol runs FIVE times - self-attention out-projection,
     # cross-attention to_q, the batched cached-context GEMM (two per-prompt operands in one launch), FFN2 and the two-round q|k
-    # projection - and 7 is coprime to 5, so every shape is sampled equally: 30 blocks x 5 x 100 forwards / 7 = ~2140 samples per scene,
+    # projection - and 7 is coprime to 5, so every shape is sampled equally: 30 blocks x 5 x 50 (CFG-batched) forwards / 7 = ~1075 samples per scene,
     # and the event pairs do not cost the probed scene 3 % of its time as bracketing every launch did
     probe = ops.GemmProbe(dom_tile, fp8=f8, stride=7)
     ops.set_gemm_probe(probe)

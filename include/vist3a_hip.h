@@ -366,7 +366,8 @@ int v3a_depth_unproject(const float* raw, int ld, const float* cam, float* depth
 /* voxel fusion: see csrc/voxel.hip.  feat[M][ldf] f32 holds nfeat feature columns (0..nfeat-1) and the raw confidence at
  * conf_col.  Outputs sized for the worst case U = M: keys_out[M][3] i32 (lexicographically sorted unique voxel coords),
  * inverse_out[M] i32, counts_out[M] i32, voxel_pts[M][3], voxel_feat[M][ldo]; *num_voxels = U (device int).
- * *status (device int) != 0 if a coordinate fell outside [-2^20, 2^20) voxels.  anysplat.py:298-335 */
+ * *status (device int) != 0 if a coordinate fell outside [-2^20, 2^20) voxels.  anysplat.py:298-335
+ * The call SYNCHRONISES `stream` once (the per-axis coordinate range is read back to size the sort key): not capturable in a hipGraph. */
 long v3a_voxelize_workspace_bytes(long M);
 int v3a_voxelize_fuse(const float* pts, const float* feat, int ldf, int nfeat, int conf_col, long M, float voxel_size,
                       void* workspace, long workspace_bytes, int* keys_out, int* inverse_out, int* counts_out,

@@ -107,8 +107,14 @@ def test_dit_14b_config4_production_size_blocks_on_the_hip_stream(hip_lib, parit
            per_block_fp8_attention={str(k): v for k, v in errs8.items()}, block_moves_stream_by={str(k): v for k, v in moved.items()}, oracle_seconds=secs)
     print("DiT 14B, 4096 tokens, HIP-stream teacher-forced: bf16", " ".join(f"{l}:{e:.1e}" for l, e in errs.items()),
           "| fp8 attention", " ".join(f"{l}:{e:.1e}" for l, e in errs8.items()), f"(oracle {secs:.0f} s)")
-    assert max(errs.values()) < BLOCK_GATE, errs
+    # measured on MI355X: bf16 block 0 2.3e-3, blocks 13 / 26 / 39 1.2e-3 / 1.0e-3 / 8.8e-4; fp8 attention 1.5e-3 / 1.0e-3.  Block 0 stands out at
+    # this width for the reason the 8-block test's curve gives (test_dit_gpu.py: 3.5e-3 after ONE block at 14B width against 1.5e-3 at 1.3B
+    # width): in front of block 0 the stream is the small patch embedding, so the block's output IS its own contributions - three bf16-rounded
+    # branch outputs of K = 5120 / 13824 reductions - while from block 1 on the same absolute noise sits on a stream several times larger.
+    # Gates: 2x the measured block-0 figure, 1.5e-3 (the 1.3B gate) for every later block.
+    assert errs[0] < 4.6e-3 and max(v for l, v in errs.items() if l) < BLOCK_GATE, errs
     assert max(errs8.values()) < 2.5e-3, errs8      # e4m3 operands: a probability / value that straddles an e4m3 boundary moves by 6 % of itself
+    assert all(errs[l] < 0.05 * moved[l] for l in errs), (errs, moved)
 
 
 def test_vae_512_stage_blocks_and_rounding_points_on_the_hip_stream(hip_lib, parity):

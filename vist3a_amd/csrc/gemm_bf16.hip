@@ -646,6 +646,89 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const GemmP pin) {
   }
 }
 
+
+// =====================================================================================================================
+// One wave per SIMD ("w4"): 4 waves x 512 registers, 256 x 192 tile, BK = 64, hand-scheduled K loop (gemm_w4_loop.inc, generated and
+// documented by tools/gen_gemm_w4.py).  The structure of the vendor library's assembly kernels: a wave owns 128 x 96 outputs (192
+// accumulators in AGPRs), so a 16-byte fragment feeds 3-4 MFMAs instead of 2-3 (112 instead of 160 LDS reads per K tile and CU), and the
+// LDS-DMA pieces / fragment reads are placed one by one between the MFMAs of the single instruction stream each SIMD runs.
+// Same LDS image (128-byte rows, chunk ^ ((row >> 1) & 7)), same D^T accumulator orientation, same ascending-k MFMA chain per output
+// element as every other tile: bit-identical results.  Stage 1 sits 64 KiB above stage 0 so that one xor moves an address between them.
+struct W4Cfg {
+  static constexpr int BM = 256, BN = 192, STAGE = (BM + BN) * 128, STAGE1 = 65536;
+  static constexpr int AUX = STAGE1 + STAGE;            // 1 KiB bias + 1 KiB gate-scale slice of the tile (as in the ping-pong kernel)
+  static constexpr int LDS_BYTES = AUX + 2048;
+  static_assert(4 * 32 * (96 * 2 + 8) <= STAGE1, "epilogue park fits stage 0");
+};
+#define W4_A8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_w4_kernel(const GemmP pin) {
+  GemmP p = pin;
+  if (gridDim.y > 1) { p.A += blockIdx.y * p.az; p.B += blockIdx.y * p.bz; p.C += blockIdx.y * p.cz; if (p.res) p.res += blockIdx.y * p.rz; if (p.rowsq) p.rowsq += (size_t)blockIdx.y * p.M * (p.N / 32); }
+  using T = W4Cfg;
+  constexpr int BM = T::BM, BN = T::BN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int tilesN = (p.N + BN - 1) / BN, tilesM = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int tl = xcd_remap(blockIdx.x, tilesM * tilesN);
+    constexpr int GM = 4;    // grouped raster: near-square patch of tiles in flight per XCD (as gemm_pp_kernel)
+    const int gsz = GM * tilesN, gid = tl / gsz, first = gid * GM;
+    const int gm = min(tilesM - first, GM), r = tl - gid * gsz;
+    m0 = (first + r % gm) * BM; n0 = (r / gm) * BN;
+  }
+  EpiAux aux;
+  aux.m0 = m0; aux.n0 = n0;
+  {
+    const bool brow = (p.flags & V3A_GEMM_BIAS_ROW) != 0;
+    const int blim = brow ? p.M : p.N;
+    if (p.bias && blim % 4 == 0) {
+      aux.lds_bias = smem + T::AUX;
+      if (wave == 0) glds16(p.bias + min((brow ? m0 : n0) + lane * 4, blim - 4), smem + T::AUX);
+    }
+    if (p.scale) {
+      const int b0 = (p.flags & V3A_GEMM_SCALE_PER_BATCH) ? m0 / p.rpb : 0;
+      const int b1 = (p.flags & V3A_GEMM_SCALE_PER_BATCH) ? min(m0 + BM - 1, p.M - 1) / p.rpb : 0;
+      if (b0 == b1) {
+        aux.lds_scale = smem + T::AUX + 1024;
+        if (wave == 1) glds16(p.scale + (size_t)b0 * p.sstride + min(n0 + lane * 4, p.N - 4), smem + T::AUX + 1024);
+      }
+    }
+  }
+  f32x16 acc[4][3];
+  {
+    const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
+    const int sw = (l31 >> 1) & 7;
+    const unsigned vrowA = m0 + 8 * wave + (lane >> 3), vrowB = n0 + 8 * wave + (lane >> 3);
+    const unsigned vchunk = ((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7)) << 4;
+    const unsigned vk0 = lds0 + l31 * 128 + (((0 + hi) ^ sw) << 4), vk1 = lds0 + l31 * 128 + (((2 + hi) ^ sw) << 4);
+    const unsigned vk2 = lds0 + l31 * 128 + (((4 + hi) ^ sw) << 4), vk3 = lds0 + l31 * 128 + (((6 + hi) ^ sw) << 4);
+    const unsigned sdma = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+    const unsigned sAoff = __builtin_amdgcn_readfirstlane(wm * 16384), sBoff = __builtin_amdgcn_readfirstlane(32768 + wn * 12288);
+    const int sM1 = p.M - 1, sN1 = p.N - 1, slda2 = p.lda * 2, sldb2 = p.ldb * 2, snk = p.K / 64;
+    const char* sA = p.A;
+    const char* sB = p.B;
+    asm volatile(
+#include "gemm_w4_loop.inc"
+        : "=&{v[0:15]}"(acc[0][0]), "=&{v[16:31]}"(acc[0][1]), "=&{v[32:47]}"(acc[0][2]), "=&{v[48:63]}"(acc[1][0]), "=&{v[64:79]}"(acc[1][1]),
+          "=&{v[80:95]}"(acc[1][2]), "=&{v[96:111]}"(acc[2][0]), "=&{v[112:127]}"(acc[2][1]), "=&{v[128:143]}"(acc[2][2]),
+          "=&{v[144:159]}"(acc[3][0]), "=&{v[160:175]}"(acc[3][1]), "=&{v[176:191]}"(acc[3][2])
+        : "s"(sA), "s"(sB), "v"(vrowA), "v"(vrowB), "v"(vchunk), "s"(sM1), "s"(sN1), "s"(slda2), "s"(sldb2), "s"(snk), "s"(sdma), "v"(vk0), "v"(vk1),
+          "v"(vk2), "v"(vk3), "s"(sAoff), "s"(sBoff)
+        : "memory", "m0", "scc", "vcc", "s60", "s61", "s62", "s63", "s64", "s65", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9",
+          W4_A8(1), W4_A8(2), W4_A8(3), W4_A8(4), W4_A8(5), W4_A8(6), W4_A8(7), W4_A8(8), W4_A8(9), W4_A8(10), W4_A8(11), W4_A8(12), W4_A8(13),
+          W4_A8(14), W4_A8(15), W4_A8(16), W4_A8(17), W4_A8(18), "a190", "a191");
+  }
+  // (every fragment read returned before the loop's last barrier and no LDS-DMA is in flight: the stages are free for the epilogue's park)
+  const int em = m0 + wm * 128, en = n0 + wn * 96;
+  gemm_add_bias<4, 3>(p, acc, lane, em, en, aux);
+  gemm_row_sumsq<4, 3>(p, acc, lane, em, en);
+  gemm_epilogue<4, 3, 3, false>(p, acc, smem, wave, lane, em, en, aux);
+}
+
 typedef void (*gemm_fn)(const GemmP);
 struct TileEntry {
   const char* name;
@@ -692,8 +775,11 @@ const TileEntry kTiles[] = {
     // 13: tile 6 with the transposed tail (v3a_gemm_args.C_t: the fused q | k | v projection of a DiT block - 512 + 256 tiles = three full rounds
     //     in ONE launch instead of a two-round and a one-round launch); identical to tile 6 when C_t is NULL
     { "pp_np3_ratrue_l5_tt", 256, 192, 512, PPCfg<3>::LDS_BYTES, (gemm_fn)gemm_pp_kernel<3, true, 5, false, true>, nullptr, nullptr },
+    // 14: one wave per SIMD, hand-scheduled K loop (gemm_w4_kernel): 256x192, 4 waves x 512 registers
+    { "w4_256x192", 256, 192, 256, W4Cfg::LDS_BYTES, (gemm_fn)gemm_w4_kernel, nullptr, nullptr },
 };
 constexpr int kTileTT = 13;
+constexpr int kTileW4 = 14;
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 // e4m3 forms of the ping-pong tiles (K tile = 128 elements: the same bytes per row, twice the matrix rate)
 #define PP8_ENTRY(NP, RA, LEAD)                                                                     \
@@ -752,6 +838,9 @@ int launch(const GemmP& p, int ti, int conv, void* stream, int nz = 1) {   // co
   const TileEntry& e = kTiles[ti];
   const gemm_fn fn = conv == 2 ? e.split_fn : conv ? e.conv_fn : e.fn;
   if (!fn) return V3A_ERR_ARG;  // this tile shape has no conv instantiation
+  // the hand-scheduled loop addresses an operand as 64-bit base + 32-bit per-lane byte offset (row * ld * 2 + chunk), 24-bit multiplicands
+  if (ti == kTileW4 && ((double)p.M * p.lda * 2 + 256 >= 4294967296.0 || (double)p.N * p.ldb * 2 + 256 >= 4294967296.0 || p.M >= (1 << 24) ||
+                        p.N >= (1 << 24) || p.lda >= (1 << 23) || p.ldb >= (1 << 23))) return V3A_ERR_SHAPE;
   const int lds = e.lds + (conv ? p.K / 8 * 4 : 0);
   if (lds > 160 * 1024) return V3A_ERR_SHAPE;
   if (g_attr_lds[ti][conv] < lds) {

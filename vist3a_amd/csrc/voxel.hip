@@ -2,9 +2,13 @@
 //   /root/reference/third_party_model/anysplat/src/model/encoder/anysplat.py:298-335 (voxelizaton_with_fusion)
 //   = (pts/voxel).round().int()  ->  torch.unique(dim=0, return_inverse, return_counts)  ->  torch_scatter
 //     scatter_max / scatter_add softmax over the per-point confidence  ->  weighted sums of xyz and features.
-// Integer part is bit-exact by construction: IEEE divide + round-half-even, a 63-bit lexicographic key
-// ((kx+2^20)<<42 | (ky+2^20)<<21 | (kz+2^20)) sorted with a stable LSD radix sort (rocPRIM device primitive, the one
-// library call in this file), run-length boundaries by an exclusive scan.  Because the sort is stable, every voxel's
+// Integer part is bit-exact by construction: IEEE divide + round-half-even, a lexicographic (x, y, z) key sorted with a stable
+// LSD radix sort (rocPRIM device primitive, the one library call in this file), run-length boundaries by an exclusive scan.
+// The key is COMPACT: a first pass takes the per-axis minimum and maximum voxel coordinate, the host reads the six integers
+// back (one 24-byte copy + stream synchronise - the caller reads the voxel count back right after this call anyway) and the
+// key packs (kx - min_x, ky - min_y, kz - min_z) into exactly bits(x) + bits(y) + bits(z) bits: a 13-view scene spans a few
+// thousand voxels per axis (~36 key bits), and the radix sort walks only those instead of all 63 of the fixed (k + 2^20) << {42, 21, 0}
+// layout it replaces - same order, same outputs, ~40 % fewer sort passes.  Because the sort is stable, every voxel's
 // points appear in ascending original index: the float sums have ONE defined order (the reference's CUDA atomics
 // have none).  The fusion pass is a segmented reduction over fixed chunks of the sorted points (see fuse_chunk_kernel).
 #include "common.h"
@@ -17,19 +21,39 @@ namespace {
 
 constexpr int KB = 1 << 20;  // coordinate bias: keys must lie in [-2^20, 2^20)
 
-struct KeyP { const float* pts; float vs; long M; unsigned long long* key; unsigned int* idx; int* bad; };
+// voxel coordinate of one component: torch's (pts / voxel_size).round().int() - IEEE divide, round half to even, truncation of an
+// integral float; out-of-range values are clamped and flagged
+__device__ __forceinline__ int voxel_coord(float x, float vs, int* bad) {
+  const float q = rintf(__fdiv_rn(x, vs));
+  int v = (int)q;
+  if (!(q >= (float)-KB && q < (float)KB)) { atomicOr(bad, 1); v = q < 0 ? -KB : KB - 1; }
+  return v;
+}
+
+// pass 1: per-axis range of the voxel coordinates, mm = {min x, min y, min z, max x, max y, max z} (wave-reduced, one atomic pair per wave and axis)
+struct RangeP { const float* pts; float vs; long M; int* mm; int* bad; };
+__global__ __launch_bounds__(256) void coord_range_kernel(const RangeP p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < p.M;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int v = on ? voxel_coord(p.pts[i * 3 + e], p.vs, p.bad) : 0;
+    int lo = on ? v : 0x7fffffff, hi = on ? v : (int)0x80000000;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(p.mm + e, lo); atomicMax(p.mm + 3 + e, hi); }
+  }
+}
+
+// pass 2: compact lexicographic key ((kx - min_x) << (by + bz)) | ((ky - min_y) << bz) | (kz - min_z)
+struct KeyP { const float* pts; float vs; long M; unsigned long long* key; unsigned int* idx; int* bad; int mn[3]; int by, bz; };
 __global__ __launch_bounds__(256) void make_keys_kernel(const KeyP p) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.M) return;
-  unsigned long long k = 0;
-#pragma unroll
-  for (int e = 0; e < 3; ++e) {
-    const float q = rintf(__fdiv_rn(p.pts[i * 3 + e], p.vs));  // torch: (pts / voxel_size).round()  (half to even)
-    int v = (int)q;                                            // .int(): truncation of an integral float
-    if (!(q >= (float)-KB && q < (float)KB)) { atomicOr(p.bad, 1); v = q < 0 ? -KB : KB - 1; }
-    k = (k << 21) | (unsigned long long)(unsigned)(v + KB);
-  }
-  p.key[i] = k;
+  const unsigned long long x = (unsigned)(voxel_coord(p.pts[i * 3 + 0], p.vs, p.bad) - p.mn[0]);
+  const unsigned long long y = (unsigned)(voxel_coord(p.pts[i * 3 + 1], p.vs, p.bad) - p.mn[1]);
+  const unsigned long long z = (unsigned)(voxel_coord(p.pts[i * 3 + 2], p.vs, p.bad) - p.mn[2]);
+  p.key[i] = (x << (p.by + p.bz)) | (y << p.bz) | z;
   p.idx[i] = (unsigned)i;
 }
 
@@ -42,7 +66,7 @@ __global__ __launch_bounds__(256) void heads_kernel(const HeadP p) {
 
 struct SegP {
   const unsigned long long* key; const unsigned int* idx; const unsigned int* head; const unsigned int* vid;  // vid = inclusive scan of head
-  long M; int* keys_out; int* inverse; unsigned int* start; int* U;
+  long M; int* keys_out; int* inverse; unsigned int* start; int* U; int mn[3]; int by, bz;
 };
 __global__ __launch_bounds__(256) void segments_kernel(const SegP p) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -52,9 +76,9 @@ __global__ __launch_bounds__(256) void segments_kernel(const SegP p) {
   if (p.head[i]) {
     p.start[u] = (unsigned)i;
     const unsigned long long k = p.key[i];
-    p.keys_out[u * 3 + 0] = (int)((k >> 42) & 0x1fffff) - KB;
-    p.keys_out[u * 3 + 1] = (int)((k >> 21) & 0x1fffff) - KB;
-    p.keys_out[u * 3 + 2] = (int)(k & 0x1fffff) - KB;
+    p.keys_out[u * 3 + 0] = (int)(k >> (p.by + p.bz)) + p.mn[0];
+    p.keys_out[u * 3 + 1] = (int)((k >> p.bz) & ((1ull << p.by) - 1)) + p.mn[1];
+    p.keys_out[u * 3 + 2] = (int)(k & ((1ull << p.bz) - 1)) + p.mn[2];
   }
   if (i == p.M - 1) { *p.U = (int)(u + 1); p.start[u + 1] = (unsigned)p.M; }
 }
@@ -301,16 +325,28 @@ extern "C" int v3a_voxelize_fuse(const float* pts, const float* feat, int ldf, i
   auto* start = (unsigned int*)(ws + l.start);
   const unsigned nb = (unsigned)((M + 255) / 256);
   if (hipMemsetAsync(status, 0, sizeof(int), stream) != hipSuccess) return V3A_ERR_LAUNCH;
-  hipLaunchKernelGGL(make_keys_kernel, dim3(nb), dim3(256), 0, stream, KeyP{pts, voxel_size, M, key_in, idx_in, status});
+  // per-axis coordinate range -> host (the one synchronisation of this call; `head` is free until the sort has run)
+  int* mm = (int*)head;
+  const int mm_init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+  if (hipMemcpyAsync(mm, mm_init, sizeof(mm_init), hipMemcpyHostToDevice, stream) != hipSuccess) return V3A_ERR_LAUNCH;
+  hipLaunchKernelGGL(coord_range_kernel, dim3(nb), dim3(256), 0, stream, RangeP{pts, voxel_size, M, mm, status});
+  int h[6];
+  if (hipMemcpyAsync(h, mm, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+    return V3A_ERR_LAUNCH;
+  auto bits = [](long span) { int b = 0; while ((1L << b) <= span) ++b; return b; };   // bits that hold 0 .. span
+  const int bx = bits((long)h[3] - h[0]), by = bits((long)h[4] - h[1]), bz = bits((long)h[5] - h[2]);   // <= 21 each (coordinates are clamped to +-2^20)
+  const int key_bits = bx + by + bz > 0 ? bx + by + bz : 1;
+  KeyP kp{pts, voxel_size, M, key_in, idx_in, status, {h[0], h[1], h[2]}, by, bz};
+  hipLaunchKernelGGL(make_keys_kernel, dim3(nb), dim3(256), 0, stream, kp);
   size_t tb = l.tmp_bytes;
-  if (rocprim::radix_sort_pairs(ws + l.tmp, tb, key_in, key_out, idx_in, idx_out, (size_t)M, 0, 63, stream) != hipSuccess)
+  if (rocprim::radix_sort_pairs(ws + l.tmp, tb, key_in, key_out, idx_in, idx_out, (size_t)M, 0, (unsigned)key_bits, stream) != hipSuccess)
     return V3A_ERR_LAUNCH;
   hipLaunchKernelGGL(heads_kernel, dim3(nb), dim3(256), 0, stream, HeadP{key_out, head, M});
   tb = l.tmp_bytes;
   if (rocprim::inclusive_scan(ws + l.tmp, tb, head, vid, (size_t)M, rocprim::plus<unsigned int>(), stream) != hipSuccess)
     return V3A_ERR_LAUNCH;
   hipLaunchKernelGGL(segments_kernel, dim3(nb), dim3(256), 0, stream,
-                     SegP{key_out, idx_out, head, vid, M, keys_out, inverse_out, start, num_voxels});
+                     SegP{key_out, idx_out, head, vid, M, keys_out, inverse_out, start, num_voxels, {h[0], h[1], h[2]}, by, bz});
   // after the sort key_in (8 M bytes) is free: the sorted confidences and the per-voxel maxima live there
   float* csorted = (float*)key_in;
   float* vmax = csorted + M;
