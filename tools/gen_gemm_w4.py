@@ -24,9 +24,14 @@ Registers (physical, named in the text): a[0:191] accumulators, block (i, j) at 
 v[32:55] B fragments (2 x 3), v56-59 / v60-63 A / B read addresses per k-step, v64-71 / v72-77 per-lane global byte offsets of the 8 A / 6 B
 pieces, v78 scratch; s[60:61] / s[62:63] A / B bases (advance 128 B per K tile), s64 the wave's LDS-DMA base of the stage being filled, s65 loop count.
 v0-v191 are the statement's (early-clobber) outputs: free as scratch inside the loop, loaded from the AGPRs at the very end."""
+import os
+import sys
 from pathlib import Path
 
-OUT = Path(__file__).resolve().parents[1] / "vist3a_amd" / "csrc" / "gemm_w4_loop.inc"
+OUT = Path(sys.argv[1]) if len(sys.argv) > 1 else Path(__file__).resolve().parents[1] / "vist3a_amd" / "csrc" / "gemm_w4_loop.inc"
+# development ablations of the steady-state loop bodies (W4_ABL=<mask> python tools/gen_gemm_w4.py /tmp/x.inc; results are garbage, timing only):
+# 1 = no LDS-DMA pieces, 2 = no vmcnt wait in front of the barrier, 4 = no fragment reads, 8 = no barrier
+ABL = int(os.environ.get("W4_ABL", "0"))
 
 # operand numbers of the asm statement (outputs 0..11 = acc blocks; inputs follow) - must match gemm_w4_kernel in gemm_bf16.hip
 OPS = dict(sA=12, sB=13, vrowA=14, vrowB=15, vchunk=16, sM1=17, sN1=18, slda2=19, sldb2=20, snk=21, sdma=22, vK0=23, vK1=24, vK2=25, vK3=26,
@@ -120,31 +125,36 @@ def body(with_dma, label):
         e(*m0_for(A[0]))
         order = [(f0, s, p) for s, p in zip(slotsA, A)] + [(f1, s, p) for s, p in zip(slotsB, B)]
         for idx, (f, s_, p) in enumerate(order):
+            if ABL & 1:
+                break
             f[s_].append(dma(p))
             if idx + 1 < len(order):
                 f[s_].append(m0_for(order[idx + 1][2]))
     for k in range(7):
+        if ABL & 4:
+            break
         f0[k].append(rd0[k])
         f1[k].append(rd1[k])
     region(1, f0, note=f"R0: k-step 3 of the previous tile (F1) | {'pieces A0-A7 of the next tile, ' if with_dma else ''}reads of k-step 0 -> F0")
     e("s_waitcnt lgkmcnt(0)")
     region(0, f1, note=f"R1: k-step 0 (F0) | {'pieces B0-B5, ' if with_dma else ''}reads of k-step 1 -> F1")
     e("s_waitcnt lgkmcnt(0)")
-    f2 = {k: [reads(2, 0)[k]] for k in range(7)}
+    f2 = {k: ([] if ABL & 4 else [reads(2, 0)[k]]) for k in range(7)}
     if with_dma:
         adv = advance_and_toggle()
         f2[8], f2[9], f2[10] = adv[0:2], adv[2:4], adv[4:5]
     region(1, f2, note="R2: k-step 1 (F1) | reads of k-step 2 -> F0" + (", operand bases += 128 B, DMA stage toggled" if with_dma else ""))
     e("s_waitcnt lgkmcnt(0)")
-    f3 = {k: [reads(3, 1)[k]] for k in range(7)}
+    f3 = {k: ([] if ABL & 4 else [reads(3, 1)[k]]) for k in range(7)}
     tg = toggle_reads()
     for k in range(4):
         f3[7 + k] = tg[2 * k: 2 * k + 2]
     if with_dma:
         f3[11] = [("s_sub_u32 s65, s65, 1", "tiles left for this loop")]
     region(0, f3, note="R3: k-step 2 (F0) | reads of k-step 3 -> F1, read addresses -> other stage")
-    e("s_waitcnt vmcnt(0) lgkmcnt(0)", "this wave's pieces of the next tile have landed; its last fragment reads have returned")
-    e("s_barrier", "... for every wave: the next tile is complete, the stage just read may be refilled")
+    e("s_waitcnt lgkmcnt(0)" if ABL & 2 else "s_waitcnt vmcnt(0) lgkmcnt(0)", "this wave's pieces of the next tile have landed; its last fragment reads have returned")
+    if not ABL & 8:
+        e("s_barrier", "... for every wave: the next tile is complete, the stage just read may be refilled")
 
 
 def generate():

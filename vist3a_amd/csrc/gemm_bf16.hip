@@ -711,8 +711,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int sM1 = p.M - 1, sN1 = p.N - 1, slda2 = p.lda * 2, sldb2 = p.ldb * 2, snk = p.K / 64;
     const char* sA = p.A;
     const char* sB = p.B;
+#ifndef W4_LOOP_INC
+#define W4_LOOP_INC "gemm_w4_loop.inc"
+#endif
     asm volatile(
-#include "gemm_w4_loop.inc"
+#include W4_LOOP_INC
         : "=&{v[0:15]}"(acc[0][0]), "=&{v[16:31]}"(acc[0][1]), "=&{v[32:47]}"(acc[0][2]), "=&{v[48:63]}"(acc[1][0]), "=&{v[64:79]}"(acc[1][1]),
           "=&{v[80:95]}"(acc[1][2]), "=&{v[96:111]}"(acc[2][0]), "=&{v[112:127]}"(acc[2][1]), "=&{v[128:143]}"(acc[2][2]),
           "=&{v[144:159]}"(acc[3][0]), "=&{v[160:175]}"(acc[3][1]), "=&{v[176:191]}"(acc[3][2])
@@ -726,7 +729,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int em = m0 + wm * 128, en = n0 + wn * 96;
   gemm_add_bias<4, 3>(p, acc, lane, em, en, aux);
   gemm_row_sumsq<4, 3>(p, acc, lane, em, en);
-  gemm_epilogue<4, 3, 3, false>(p, acc, smem, wave, lane, em, en, aux);
+#ifndef W4_EPI_DBG
+#define W4_EPI_DBG 0
+#endif
+  gemm_epilogue<4, 3, 3, false, W4_EPI_DBG>(p, acc, smem, wave, lane, em, en, aux);
 }
 
 typedef void (*gemm_fn)(const GemmP);

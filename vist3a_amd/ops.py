@@ -5,6 +5,7 @@ libvist3a_hip.so.  Every wrapper validates dtype/device/contiguity and raises on
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import Optional
 
@@ -89,6 +90,9 @@ def set_flop_meter(m: Optional[FlopMeter]) -> None:
 
 
 _gemm_ws = {}   # per (device, thread) split-K partial buffer (see _attn_ws)
+# development A/B knob: V3A_TILE_OVERRIDE="MxNxK:tile,..." forces a tile for plain launches (tile = -1, no batch / split-K / transposed tail) of a shape
+_tile_override = {tuple(int(v) for v in e.split(":")[0].split("x")): int(e.split(":")[1])
+                  for e in os.environ.get("V3A_TILE_OVERRIDE", "").split(",") if ":" in e}
 
 
 def gemm(
@@ -179,6 +183,8 @@ def gemm(
         ldr = residual.stride(0)
     if out_f32:
         flags |= L.GEMM_OUT_F32
+    if _tile_override and tile < 0 and batch is None and split_k == 1 and t_out is None and a_scale is None:
+        tile = _tile_override.get((M, N, K), tile)
     args = L.GemmArgs(
         _ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(scale),
         M, N, K, a.stride(0), w.stride(0), out.stride(0), ldr,
