@@ -29,6 +29,9 @@ python tools/gemm_sweep.py 6,8,7 0,1,2,3,4,8 2>/dev/null | grep "^{" > $O/prof_g
 python tools/gemm_fp8_time.py 2>/dev/null | grep "^{" > $O/prof_gemm_fp8.jsonl
 python tools/attn_time.py 2x12x4096 2x12x6144 2>/dev/null | grep '^{' > $O/prof_attn_time.jsonl
 python tools/xprobs_time.py 2>/dev/null | grep '^{' > $O/prof_xprobs_time.jsonl
+python tools/norm_time.py 2>/dev/null | grep '^{' > $O/prof_norm_time.jsonl            # the row passes beside the copy yardstick of the same box
+python tools/voxel_time.py 2>/dev/null | grep '^{' > $O/prof_voxel_time.jsonl          # compact sort key (round 6)
+python tools/gemm_sweep.py 6,14 0,1,2,3,8 2>/dev/null | grep "^{" > $O/prof_gemm_sweep_w4.jsonl   # ping-pong tile vs the one-wave-per-SIMD tile
 python tools/conv_sweep.py 2>/dev/null | tail -2 > $O/prof_conv_sweep.txt
 python tools/vae_time.py 2>/dev/null | tail -2 > $O/prof_vae_time.jsonl
 python tools/recon_time.py 2>/dev/null | tail -2 > $O/prof_recon_time.jsonl

@@ -30,18 +30,37 @@ __device__ __forceinline__ int voxel_coord(float x, float vs, int* bad) {
   return v;
 }
 
-// pass 1: per-axis range of the voxel coordinates, mm = {min x, min y, min z, max x, max y, max z} (wave-reduced, one atomic pair per wave and axis)
+// pass 1: per-axis range of the voxel coordinates, mm = {min x, min y, min z, max x, max y, max z}.  A fixed grid of workgroups walks the points
+// with a grid stride (coalesced 12-byte rows), reduces in registers, across the wave, across the workgroup's four waves through LDS, and issues SIX atomics
+// per WORKGROUP: 6 k atomics per call on six addresses instead of one set per wave (245 k of them serialised in L2: 2.8 ms on 2.6 M points).
+constexpr int RANGE_BLOCKS = 1024;
 struct RangeP { const float* pts; float vs; long M; int* mm; int* bad; };
 __global__ __launch_bounds__(256) void coord_range_kernel(const RangeP p) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool on = i < p.M;
+  __shared__ int red[4][6];
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.M; i += (long)gridDim.x * 256) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int v = voxel_coord(p.pts[i * 3 + e], p.vs, p.bad);
+      lo[e] = min(lo[e], v); hi[e] = max(hi[e], v);
+    }
+  }
 #pragma unroll
   for (int e = 0; e < 3; ++e) {
-    const int v = on ? voxel_coord(p.pts[i * 3 + e], p.vs, p.bad) : 0;
-    int lo = on ? v : 0x7fffffff, hi = on ? v : (int)0x80000000;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { atomicMin(p.mm + e, lo); atomicMax(p.mm + 3 + e, hi); }
+    for (int o = 32; o > 0; o >>= 1) { lo[e] = min(lo[e], __shfl_xor(lo[e], o, 64)); hi[e] = max(hi[e], __shfl_xor(hi[e], o, 64)); }
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { red[wave][e] = lo[e]; red[wave][3 + e] = hi[e]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int e = threadIdx.x;
+    int v = red[0][e];
+    for (int w = 1; w < 4; ++w) v = e < 3 ? min(v, red[w][e]) : max(v, red[w][e]);
+    if (e < 3) atomicMin(p.mm + e, v); else atomicMax(p.mm + e, v);
   }
 }
 
@@ -329,7 +348,7 @@ extern "C" int v3a_voxelize_fuse(const float* pts, const float* feat, int ldf, i
   int* mm = (int*)head;
   const int mm_init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, (int)0x80000000, (int)0x80000000, (int)0x80000000};
   if (hipMemcpyAsync(mm, mm_init, sizeof(mm_init), hipMemcpyHostToDevice, stream) != hipSuccess) return V3A_ERR_LAUNCH;
-  hipLaunchKernelGGL(coord_range_kernel, dim3(nb), dim3(256), 0, stream, RangeP{pts, voxel_size, M, mm, status});
+  hipLaunchKernelGGL(coord_range_kernel, dim3(nb < (unsigned)RANGE_BLOCKS ? nb : (unsigned)RANGE_BLOCKS), dim3(256), 0, stream, RangeP{pts, voxel_size, M, mm, status});
   int h[6];
   if (hipMemcpyAsync(h, mm, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
     return V3A_ERR_LAUNCH;
