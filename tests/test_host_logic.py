@@ -12,6 +12,14 @@ import torch
 ROOT = Path(__file__).resolve().parents[1]
 
 
+def _free_port() -> str:
+    """a TCP port the kernel just handed out (fixed rendezvous ports collide with a previous run's sockets in TIME_WAIT)"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
+
 def test_conv_spec_grammar():
     from vist3a_amd.models.stitching_layer_builder import ConvSpec, parse_conv_spec
     s = parse_conv_spec("conv3d_k5x3x3_o1024_s1x2x2_p2x1x1")
@@ -110,7 +118,7 @@ def test_prompt_sharding_world_size_2_gloo(tmp_path):
     script.write_text(_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29617", str(script), str(ROOT)], capture_output=True, text=True, timeout=240, env=env)
+                        "--master-port", _free_port(), str(script), str(ROOT)], capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
     line = [l for l in r.stdout.splitlines() if l.startswith("[[")][-1]
@@ -164,7 +172,7 @@ def test_denoise_plan_world_size_2_gloo(tmp_path):
     script.write_text(_SP_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29633", str(script), str(ROOT)], capture_output=True, text=True, timeout=240, env=env)
+                        "--master-port", _free_port(), str(script), str(ROOT)], capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
     line = [l for l in r.stdout.splitlines() if l.startswith("[")][-1]
@@ -231,7 +239,7 @@ def test_seq_parallel_slab_addressing_at_production_shard_shape_gloo(tmp_path):
     script.write_text(_SP_SHAPE_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", OMP_NUM_THREADS="4")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29641", str(script), str(ROOT)], capture_output=True, text=True, timeout=600, env=env)
+                        "--master-port", _free_port(), str(script), str(ROOT)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
     line = [l for l in r.stdout.splitlines() if l.startswith("[")][-1]
@@ -484,7 +492,7 @@ def test_view_sharded_reconstruction_exchange_world_size_2_gloo(tmp_path):
     script.write_text(_VIEW_SHARD_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29641", str(script), str(ROOT)], capture_output=True, text=True, timeout=240, env=env)
+                        "--master-port", _free_port(), str(script), str(ROOT)], capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
     line = [l for l in r.stdout.splitlines() if l.startswith("[")][-1]
