@@ -25,6 +25,8 @@ bash tools/pmc_mfma.sh > /dev/null 2>&1; cp $O/pmc_mfma.json $O/prof_pmc_mfma.js
 python tools/dit14b_time.py 2>/dev/null | tail -4 > $O/prof_dit14b.jsonl
 python tools/sp_rank_time.py 2>/dev/null | tail -8 > $O/prof_sp_rank_time_1_3b.jsonl
 python tools/sp_rank_time.py 14b 2>/dev/null | tail -8 > $O/prof_sp_rank_time_14b.jsonl
+python tools/sp_rank_time.py 14b fp8 2>/dev/null | tail -8 > $O/prof_sp_rank_time_14b_fp8.jsonl
+python tools/sp_rank_time.py views21 2>/dev/null | tail -8 > $O/prof_sp_rank_time_views21.jsonl
 python tools/gemm_sweep.py 6,8,7 0,1,2,3,4,8 2>/dev/null | grep "^{" > $O/prof_gemm_sweep.jsonl
 python tools/gemm_fp8_time.py 2>/dev/null | grep "^{" > $O/prof_gemm_fp8.jsonl
 python tools/attn_time.py 2x12x4096 2x12x6144 2>/dev/null | grep '^{' > $O/prof_attn_time.jsonl

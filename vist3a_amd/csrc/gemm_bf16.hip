@@ -783,6 +783,16 @@ const TileEntry kTiles[] = {
     { "pp_np3_ratrue_l5_tt", 256, 192, 512, PPCfg<3>::LDS_BYTES, (gemm_fn)gemm_pp_kernel<3, true, 5, false, true>, nullptr, nullptr },
     // 14: one wave per SIMD, hand-scheduled K loop (gemm_w4_kernel): 256x192, 4 waves x 512 registers
     { "w4_256x192", 256, 192, 256, W4Cfg::LDS_BYTES, (gemm_fn)gemm_w4_kernel, nullptr, nullptr },
+    // 15-17: the small tiles with a FOUR-deep LDS ring.  A sequence-parallel shard's projection (512-2048 rows) is one short chain of 24 K slabs per
+    // workgroup with few workgroups per CU: with two stages every slab exposes its LDS-DMA latency (0.6 us per slab whatever the load - a 512-row launch
+    // takes as long as a 1024-row one); with slabs kt+1 .. kt+2 in flight across the barrier the chain runs at the tile's LDS / MFMA rate
+    TILE_ENTRY(64, 64, 2, 2, 64, 4),    // 15
+    TILE_ENTRY(128, 64, 2, 2, 64, 4),   // 16
+    TILE_ENTRY(64, 128, 2, 2, 64, 4),   // 17
+    // 18-19: the 128 x 256 / 256 x 128 lockstep tiles with a THREE-deep ring (147 KB: one workgroup per CU) - the Wan-14B shard projections
+    // (1024 x 5120 x 5120: 160 workgroups, 80 K slabs each, 52 MB of weights cold per launch)
+    TILE_ENTRY(128, 256, 2, 4, 64, 3),  // 18
+    TILE_ENTRY(256, 128, 4, 2, 64, 3),  // 19
 };
 constexpr int kTileTT = 13;
 constexpr int kTileW4 = 14;
@@ -826,6 +836,21 @@ int pick_tile(int M, int N, bool conv = false, int mult = 1, int act = 0) {
     // faster than 256x192 on FFN1 (-1.0 % on the whole DiT step); without one it is 3 % slower: break the tie by the activation
     if (i == 8 && act != V3A_ACT_NONE && act != V3A_ACT_RELU) cost *= 0.999;
     if (cost < best - 1e-9) { best = cost; bi = i; }
+  }
+  // A small-tile launch with at most two (64 x 64) / one (128 x 64, 64 x 128) workgroups per CU is a sequence-parallel shard's projection or
+  // a similar short problem: each workgroup is one chain of K slabs over weights nobody has touched since the last forward, and with two LDS
+  // stages every slab exposes its DMA latency.  The four-deep ring (tiles 15-17, bit-identical) keeps two more slabs in flight: measured inside
+  // the P = 4 sharded DiT forward 9.27 -> 8.61 ms (profiles/r6/sp_tile_ab.log); back to back on hot weights it is neutral, and with more
+  // workgroups per CU than its 64 / 96 KB of LDS admit it loses (2048 x 1536 x 1536: 18.2 -> 22.5 us) - hence the bound.
+  if (!conv) {
+    const long wgs = (long)((M + kTiles[bi].BM - 1) / kTiles[bi].BM) * ((N + kTiles[bi].BN - 1) / kTiles[bi].BN) * mult;
+    if (bi == 11 && wgs <= 512) bi = 15;
+    else if (bi == 10 && wgs <= 256) bi = 16;
+    else if (bi == 9 && wgs <= 256) bi = 17;
+    // the same for the 128 x 256 / 256 x 128 tiles at one workgroup per CU (a Wan-14B shard's 1024 x 5120 x 5120 projections: 160 workgroups of
+    // 80 K slabs over 52 MB of cold weights): three-deep ring, P = 4 forward 48.8 -> 43.5 ms (profiles/r6/sp_tile_ab_14b.log)
+    else if (bi == 3 && wgs <= 256) bi = 18;
+    else if (bi == 4 && wgs <= 256) bi = 19;
   }
   return bi;
 }

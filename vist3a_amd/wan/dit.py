@@ -17,6 +17,7 @@ MI355X-first choices (none of them inherited from the PyTorch module graph):
 from __future__ import annotations
 
 import math
+import os
 import threading
 from collections import OrderedDict
 from dataclasses import dataclass
@@ -138,6 +139,7 @@ class WanDiT:
         self._ctx: "OrderedDict[tuple, tuple]" = OrderedDict()
         self.max_ctx_slots = 2
         self._ctx_serial = 0
+        self.sp_split_k = os.environ.get("V3A_SP_SPLIT_K", "1") != "0"   # sequence-parallel shards: FFN2 as split-K partials + finish (see _sp_ksplit)
         self._ctx_lock = threading.Lock()   # virtual ranks (threads) look up / evict concurrently
         self.merge_padding_keys = True      # see _context
         # "fp8": self-attention on the block-scaled fp8 MFMA (BASELINE config #4; csrc/attention_fp8.hip): q / k (after RMSNorm + RoPE)
@@ -166,7 +168,7 @@ class WanDiT:
 
     def _sp_ksplit(self, M: int, N: int, K: int) -> int:
         """split-K factor of a shard's long-K projection (FFN2): few output tiles, 140 K tiles each - unless the exact mode is on"""
-        if self.sp_kv_split == 1 or M > 2048 or K < 4096:
+        if self.sp_kv_split == 1 or M > 2048 or K < 4096 or not self.sp_split_k:
             return 1
         for S in (4, 2):
             if K % (64 * S) == 0 and (M // 64) * (N // 64) * S <= 2048:
