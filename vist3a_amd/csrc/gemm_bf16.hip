@@ -793,6 +793,8 @@ const TileEntry kTiles[] = {
     // (1024 x 5120 x 5120: 160 workgroups, 80 K slabs each, 52 MB of weights cold per launch)
     TILE_ENTRY(128, 256, 2, 4, 64, 3),  // 18
     TILE_ENTRY(256, 128, 4, 2, 64, 3),  // 19
+    // 20: 128 x 192, four waves of 64 x 96, three-deep ring: the Wan-14B shard projections again - 8 x 27 = 216 workgroups instead of the 160 of 128 x 256
+    TILE_ENTRY(128, 192, 2, 2, 64, 3),
 };
 constexpr int kTileTT = 13;
 constexpr int kTileW4 = 14;
@@ -851,6 +853,10 @@ int pick_tile(int M, int N, bool conv = false, int mult = 1, int act = 0) {
     // 80 K slabs over 52 MB of cold weights): three-deep ring, P = 4 forward 48.8 -> 43.5 ms (profiles/r6/sp_tile_ab_14b.log)
     else if (bi == 3 && wgs <= 256) bi = 18;
     else if (bi == 4 && wgs <= 256) bi = 19;
+    if (bi == 18 || bi == 19) {   // ... and the 128 x 192 form of it when that puts more CUs to work without a second round (1024 x 5120: 216 workgroups instead of 160)
+      const long w20 = (long)((M + 127) / 128) * ((N + 191) / 192) * mult;
+      if (w20 <= 256 && w20 > wgs) bi = 20;
+    }
   }
   return bi;
 }
