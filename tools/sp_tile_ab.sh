@@ -5,7 +5,7 @@ if [ "$M" = "14b" ]; then
   S="1024x5120x5120 5120x1024x5120"
   for r in 1 2; do
     echo "base $(SP_ONLY=4 python tools/sp_rank_time.py 14b 2>/dev/null | tail -1)"
-    for t in 6 4 18 19; do
+    for t in 6 4 18 19 20; do
       o=""; for s in $S; do o="$o,$s:$t"; done
       echo "tile $t $(V3A_TILE_OVERRIDE=${o#,} SP_ONLY=4 python tools/sp_rank_time.py 14b 2>/dev/null | tail -1)"
     done
