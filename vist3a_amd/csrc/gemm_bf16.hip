@@ -795,6 +795,7 @@ const TileEntry kTiles[] = {
     TILE_ENTRY(256, 128, 4, 2, 64, 3),  // 19
     // 20: 128 x 192, four waves of 64 x 96, three-deep ring: the Wan-14B shard projections again - 8 x 27 = 216 workgroups instead of the 160 of 128 x 256
     TILE_ENTRY(128, 192, 2, 2, 64, 3),
+    TILE_ENTRY(128, 128, 2, 2, 64, 3),  // 21: 128 x 128 with a three-deep ring (96 KB: one workgroup per CU) - 2048-row shard projections (192 workgroups)
 };
 constexpr int kTileTT = 13;
 constexpr int kTileW4 = 14;
@@ -851,6 +852,7 @@ int pick_tile(int M, int N, bool conv = false, int mult = 1, int act = 0) {
     else if (bi == 9 && wgs <= 256) bi = 17;
     // the same for the 128 x 256 / 256 x 128 tiles at one workgroup per CU (a Wan-14B shard's 1024 x 5120 x 5120 projections: 160 workgroups of
     // 80 K slabs over 52 MB of cold weights): three-deep ring, P = 4 forward 48.8 -> 43.5 ms (profiles/r6/sp_tile_ab_14b.log)
+    else if (bi == 5 && wgs <= 256) bi = 21;   // 2048-row shard projections (P = 2): 13.5 -> 12.9 ms per rank forward (profiles/r6/sp_tile_ab_p2.log)
     else if (bi == 3 && wgs <= 256) bi = 18;
     else if (bi == 4 && wgs <= 256) bi = 19;
     if (bi == 18 || bi == 19) {   // ... and the 128 x 192 form of it when that puts more CUs to work without a second round (1024 x 5120: 216 workgroups instead of 160)
