@@ -49,6 +49,8 @@ if __name__ == "__main__":
     frames = 6 if "views21" in sys.argv[1:] else 4   # 21 views = 6 latent frames = 6144 tokens (BASELINE config #3)
     lat = torch.randn(1, 16, frames, 64, 64, device="cuda").bfloat16()
     import os
+    if os.environ.get("SP_KV_SPLIT"):   # A/B of the key-split factor of the shard's attention (default: WanDiT._sp_split's choice)
+        m.sp_kv_split = int(os.environ["SP_KV_SPLIT"])
     if os.environ.get("SP_ONLY"):   # profiling aid: only the sharded forward at P = SP_ONLY (rocprofv3 --kernel-trace --stats -- ...)
         sp = SelfGather(int(os.environ["SP_ONLY"]))
         print(json.dumps(dict(P=sp.world, ms=round(timed(lambda: m(lat, t, text, sp=sp)), 2))))
