@@ -64,7 +64,9 @@ typedef struct {
   int rows_per_batch, scale_stride;
   int act;              /* V3A_ACT_* */
   int flags;            /* V3A_GEMM_* */
-  int tile;             /* -1 = auto, else index into the tile table (bench/tuning) */
+  int tile;             /* -1 = auto, else index into the tile table (bench/tuning; all tiles give bit-identical results): 0-5 lockstep, 6-8 ping-pong,
+                         * 9-11 small, 12 128x96, 13 transposed tail, 14 one wave per SIMD (hand-scheduled K loop), 15-21 deep-ring forms of the
+                         * small / medium tiles (shard-size launches); v3a_gemm_tile_name(i) names them */
   const void* residual2; /* optional second residual, bf16 [M, ldr2] */
   int ldr2;
   int res_row_mod;      /* > 0: `residual` row index is (row % res_row_mod): broadcast table (positional embedding) */
